@@ -1,0 +1,195 @@
+/*
+ * monolith_hip.h — C ABI of libmonolith_hip.so, the MI355X (gfx950) replacement for the
+ * sparse-embedding hot path of Monolith's TensorFlow custom ops.
+ *
+ * Conventions
+ *   - Every data pointer is a DEVICE pointer (hipMalloc / torch.Tensor.data_ptr()) unless its
+ *     name starts with `h_` (host pointer, read before the call returns).
+ *   - Every call that launches work takes a `void* stream` (a hipStream_t; NULL = default
+ *     stream) and is stream-ordered; nothing synchronises the host unless stated.
+ *   - Return value: 0 = OK, non-zero = error; mono_last_error() gives the message of the
+ *     calling thread's last failure. No C++ exception crosses this boundary.
+ *   - Handles are opaque, owned by the caller, freed with the matching *_destroy.
+ *   - One host thread drives one GPU; calls on one handle must not overlap.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to
+ * monolith/native_training/ in 0x1997/monolith).
+ */
+#ifndef MONOLITH_HIP_H_
+#define MONOLITH_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- configuration PODs (mirror runtime/hash_table/embedding_hash_table.proto:19-87,
+ *      optimizer/optimizer.proto:19-72, initializer/initializer_config.proto:19-46) ---- */
+
+enum { MONO_OPT_SGD = 0, MONO_OPT_ADAGRAD = 1, MONO_OPT_FTRL = 2 };
+enum { MONO_INIT_ZEROS = 0, MONO_INIT_ONES = 1, MONO_INIT_CONSTANT = 2, MONO_INIT_UNIFORM = 3 };
+
+typedef struct {
+  int32_t dim;          /* EntryConfig.Segment.dim_size */
+  int32_t opt_kind;     /* MONO_OPT_* */
+  float init_acc;       /* initial_accumulator_value (Adagrad / FTRL), default 0.1 */
+  float weight_decay;   /* Adagrad weight_decay_factor, default 0 */
+  float l1;             /* FTRL l1_regularization_strength */
+  float l2;             /* FTRL l2_regularization_strength */
+  float beta;           /* FTRL beta */
+  int32_t init_kind;    /* MONO_INIT_* */
+  float init_a;         /* constant value, or uniform minval */
+  float init_b;         /* uniform maxval */
+} mono_segment_cfg;
+
+typedef struct {
+  int32_t n_segments;
+  int32_t default_expire_days;       /* SlotExpireTimeConfig.default_expire_time (36500) */
+  const mono_segment_cfg* segments;  /* host pointer, n_segments entries */
+  int64_t initial_capacity;          /* rows the table must hold before its first rehash */
+  int32_t n_slot_expire;             /* SlotExpireTimeConfig.slot_expire_times */
+  int32_t reserved;
+  const int32_t* slot_ids;           /* host pointer */
+  const int32_t* slot_expire_days;   /* host pointer */
+  uint64_t seed;                     /* seed of the random_uniform initializer */
+} mono_table_cfg;
+
+const char* mono_last_error(void);
+/* Library/ABI version, bumped when a signature changes. */
+int mono_abi_version(void);
+
+/* ---- hash filter: runtime/neo_filter/{hash_filter.h,sliding_hash_filter.cc},
+ *      ops/neo_filter_tf_bridge.cc:25-40, ops/hash_filter_op.cc:109-141 ---- */
+enum { MONO_FILTER_DUMMY = 0, MONO_FILTER_SLIDING = 1 };
+int mono_filter_create(int kind, int64_t capacity, int split_num, int default_threshold,
+                       int n_slot_thresholds, const int32_t* h_slots,
+                       const int32_t* h_thresholds, void** out_filter);
+int mono_filter_destroy(void* filter);
+/* Batch form of Filter::add (sliding_hash_filter.cc:57-89): old_counts[i] = count before the add. */
+int mono_filter_add(void* filter, const int64_t* ids, const int32_t* counts, int64_t n,
+                    int32_t* old_counts, void* stream);
+/* Filter::get (sliding_hash_filter.cc:91-113). */
+int mono_filter_get(void* filter, const int64_t* ids, int64_t n, int32_t* counts, void* stream);
+/* ops/hash_filter_intercept_gradient_op.cc:39-62 — zero the grad rows of filtered ids
+ * (every id is counted once). */
+int mono_filter_intercept_gradient(void* filter, const int64_t* ids, const float* grad, int64_t n,
+                                   int64_t width, float* out, void* stream);
+/* Host-visible filter state: h_out = {head, head_increment, failure_count, n_blocks,
+ * block_total_size, num_elements[0..n_blocks)}; synchronises the stream. */
+int mono_filter_state(void* filter, int64_t* h_out, int64_t h_out_len, void* stream);
+
+/* ---- table lifetime: ops/hash_table_op.cc:38-131, ops/embedding_hash_table_tf_bridge.cc:48-104 ---- */
+int mono_table_create(const mono_table_cfg* cfg, void** out_table);
+int mono_table_destroy(void* table);
+int mono_table_dim(void* table);         /* EmbeddingHashTableTfBridge::dim_size */
+int mono_table_slice_size(void* table);  /* ::slice_size = number of segments */
+
+/* ops/hash_table_lookup_op.cc:36-73 (MonolithHashTableLookup): out[n, dim]; miss => zeros. */
+int mono_table_lookup(void* table, const int64_t* ids, int64_t n, float* out, void* stream);
+
+/* ops/hash_table_update_op.cc:28-50 (MonolithHashTableAssign), bridge :156-184. filter may be NULL. */
+int mono_table_assign(void* table, void* filter, const int64_t* ids, const float* values,
+                      int64_t n, int64_t req_time, void* stream);
+/* ops/hash_table_update_op.cc:52-75 (MonolithHashTableAssignAdd), bridge :186-209. */
+int mono_table_assign_add(void* table, void* filter, const int64_t* ids, const float* values,
+                          int64_t n, int64_t req_time, void* stream);
+/* ops/hash_table_update_op.cc:95-164 (MonolithHashTableOptimize), bridge :229-313.
+ * h_learning_rates: host float[slice_size]. */
+int mono_table_apply_gradients(void* table, void* filter, const int64_t* ids, const float* grads,
+                               int64_t n, const float* h_learning_rates, int n_learning_rates,
+                               int64_t req_time, int64_t global_step, int enable_dedup,
+                               void* stream);
+
+/* hash_table/misc_ops.cc:38-60 (MonolithHashTableSize); synchronises the stream. */
+int mono_table_size(void* table, int64_t* h_size, void* stream);
+/* EmbeddingHashTableInterface::Contains (embedding_hash_table_interface.h:107): out[i] in {0,1}. */
+int mono_table_contains(void* table, const int64_t* ids, int64_t n, uint8_t* out, void* stream);
+/* EmbeddingHashTableInterface::Clear (cuckoo_embedding_hash_table.cc:270-273). */
+int mono_table_clear(void* table, void* stream);
+/* CuckooEmbeddingHashTable::Evict (cuckoo_embedding_hash_table.cc:220-233). */
+int mono_table_evict(void* table, int64_t max_update_time, void* stream);
+/* EmbeddingHashTableTfBridge::max_update_ts_sec (bridge :377-379). */
+int mono_table_max_update_ts(void* table, int64_t* h_out);
+/* Make room for `rows` live rows without a rehash inside a later call (the cuckoo map's
+ * reserve(): cuckoohash_map.hpp:131); may reallocate + rehash; synchronises. */
+int mono_table_reserve(void* table, int64_t rows, void* stream);
+/* Dump for save / tests (hash_table/misc_ops.cc SaveAsTensor; save-time expiry
+ * ops/hash_table_save_op.cc:142-150 when apply_expiry != 0): writes up to max_rows live rows
+ * (ids[], rows[max_rows, dim + state], ts[]) in slot order; *h_count = rows written; synchronises. */
+int mono_table_export(void* table, int64_t max_rows, int apply_expiry, int64_t* ids, float* rows,
+                      uint32_t* ts, int64_t* h_count, void* stream);
+/* Restore path (ops/hash_table_restore_op.cc:82-131): upsert full rows (value + optimizer state + ts). */
+int mono_table_import(void* table, const int64_t* ids, const float* rows, const uint32_t* ts,
+                      int64_t n, void* stream);
+/* Floats per stored row: dim + optimizer state. */
+int mono_table_row_floats(void* table);
+
+/* ops/hash_table_lookup_op.cc:148-251 (MonolithHashTableFusedLookup). h_fused_slot_size is a
+ * host int32[K*N]; the four int32 metadata outputs are host arrays; out_emb is a device buffer
+ * of at least sum(size*dim) floats (call with out_emb == NULL to get the metadata only). */
+int mono_tables_fused_lookup(void* const* tables, int K, const int64_t* ids,
+                             const int32_t* h_fused_slot_size, int N, float* out_emb,
+                             int32_t* h_emb_splits, int32_t* h_id_offsets, int32_t* h_emb_offsets,
+                             int32_t* h_emb_sizes, void* stream);
+/* ops/hash_table_update_op.cc:174-262 (MonolithHashTableFusedOptimize). */
+int mono_tables_fused_apply_gradient(void* const* tables, void* const* filters, int K,
+                                     const int64_t* ids, const int32_t* h_fused_slot_size,
+                                     const float* grads, const int32_t* h_id_offsets,
+                                     const int32_t* h_grad_offsets, const float* h_learning_rates,
+                                     const int32_t* h_lr_lengths, int64_t req_time,
+                                     int64_t global_step, int N, int enable_grad_accumulation,
+                                     void* stream);
+
+/* ---- routing / exchange ops ---- */
+/* ops/fused_reorder_by_indices.cc:36-112 + distribution_ops.py:255-272. inputs: M device id
+ * arrays (host array of device pointers); shard_rule 0 = floormod(id, N), 1 = 1 + floormod(id, N-1).
+ * out_ids has room for sum(lens) ids; *h_n_unique = ids written; out_offsets: M device int32
+ * arrays shaped like the inputs; h_shard_sizes[N], h_sharded_slot_sizes[N*M] host; synchronises. */
+int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h_lens, int M, int N,
+                                  const int32_t* h_dims, int shard_rule, int64_t* out_ids,
+                                  int64_t* h_n_unique, int32_t* h_shard_sizes,
+                                  int32_t* h_sharded_slot_sizes, int32_t* const* out_offsets,
+                                  void* stream);
+/* ops/map_id_to_embedding_op.cc:239-292 / map_id_to_embedding.cu.cc:30-74. */
+int mono_fused_gather_embeddings_by_input(const float* fused, int64_t fused_len,
+                                          const int32_t* const* offsets, const int64_t* h_lens,
+                                          const int32_t* h_dims, int M, float* const* outs,
+                                          void* stream);
+/* ops/map_id_to_embedding_op.cc:294-343 (CPU order: deterministic, in input order). */
+int mono_fused_gather_embeddings_by_input_gradient(int64_t fused_len, const float* const* grads,
+                                                   const int32_t* const* offsets,
+                                                   const int64_t* h_lens, const int32_t* h_dims,
+                                                   int M, float* out, void* stream);
+
+/* ---- pooling ---- */
+/* ops/reduce_op.cc:29-51 / :55-87: out[batch, dim] zero-filled then summed in input order. */
+int mono_reduce_sum(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
+                    int64_t batch, float* out, void* stream);
+int mono_reduce_mean(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
+                     int64_t batch, float* out, void* stream);
+/* ops/reduce_op.cc:124-148 / :150-180. */
+int mono_reduce_sum_gradient(const int64_t* row_ids, const float* grads, int64_t n, int64_t dim,
+                             int64_t batch, float* out, void* stream);
+int mono_reduce_mean_gradient(const int64_t* row_ids, const float* grads, int64_t n, int64_t dim,
+                              int64_t batch, float* out, void* stream);
+/* ops/reduce_op.cc:232-277 / :279-321. outs / grads: M device pointers. */
+int mono_fused_reduce_sum_and_split(const int64_t* row_ids, const float* values, int64_t n,
+                                    int64_t dim, int64_t batch, const int32_t* h_split_dims, int M,
+                                    float* const* outs, void* stream);
+int mono_fused_reduce_sum_and_split_gradient(const int64_t* row_ids, const float* const* grads,
+                                             int64_t n, int64_t batch, const int32_t* h_split_dims,
+                                             int M, float* out, void* stream);
+/* ops/reduce_op.cu.cc:53-161 (MonolithFusedSegmentSum): N sorted segment sums in one call. */
+int mono_fused_sorted_segment_sum(const int32_t* const* indices, const float* const* values,
+                                  const int64_t* h_lens, const int64_t* h_dims,
+                                  const int64_t* h_out_rows, int N, float* const* outs,
+                                  void* stream);
+/* embedding_combiners.py:71-100 (FirstN): out[batch, max_seq, dim], zero padded. row_ids sorted. */
+int mono_first_n(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
+                 int64_t batch, int64_t max_seq, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOLITH_HIP_H_ */

@@ -1,0 +1,23 @@
+"""Scenario back-end over the CPU oracle."""
+from oracle import cpu
+
+
+def seg_from_dict(d):
+  return cpu.seg(d["dim"], d.get("opt", "sgd"), d.get("init", "zeros"),
+                 init_acc=d.get("init_acc", 0.1), weight_decay=d.get("weight_decay", 0.0),
+                 l1=d.get("l1", 0.0), l2=d.get("l2", 0.0), beta=d.get("beta", 0.0),
+                 init_a=d.get("init_a", 0.0), init_b=d.get("init_b", 0.0))
+
+
+def make_table(cfg):
+  return cpu.OracleTable([seg_from_dict(s) for s in cfg["segments"]],
+                         initial_capacity=cfg.get("initial_capacity", 1),
+                         default_expire_days=cfg.get("default_expire_days", 36500),
+                         slot_expire={int(k): v for k, v in cfg.get("slot_expire", {}).items()},
+                         seed=cfg.get("seed", 0))
+
+
+def make_filter(cfg):
+  return cpu.OracleFilter(cfg.get("kind", "sliding"), cfg.get("capacity", 300000000),
+                          cfg.get("split_num", 7), cfg.get("default_threshold", 0),
+                          {int(k): v for k, v in cfg.get("slot_thresholds", {}).items()})
