@@ -1,0 +1,59 @@
+"""ctypes loader of libmonolith_hip.so. There is no CPU fallback: a missing or unloadable
+library raises, and every non-zero status from the C ABI raises MonolithHipError."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmonolith_hip.so")
+
+
+class MonolithHipError(RuntimeError):
+  """Raised for any non-zero status of the C ABI (the reference raises
+  tf.errors.InvalidArgumentError / ResourceExhaustedError from its Status)."""
+
+
+class SegCfg(C.Structure):  # mono_segment_cfg
+  _fields_ = [("dim", C.c_int32), ("opt_kind", C.c_int32), ("init_acc", C.c_float),
+              ("weight_decay", C.c_float), ("l1", C.c_float), ("l2", C.c_float),
+              ("beta", C.c_float), ("init_kind", C.c_int32), ("init_a", C.c_float),
+              ("init_b", C.c_float)]
+
+
+class TableCfg(C.Structure):  # mono_table_cfg
+  _fields_ = [("n_segments", C.c_int32), ("default_expire_days", C.c_int32),
+              ("segments", C.POINTER(SegCfg)), ("initial_capacity", C.c_int64),
+              ("n_slot_expire", C.c_int32), ("reserved", C.c_int32),
+              ("slot_ids", C.POINTER(C.c_int32)), ("slot_expire_days", C.POINTER(C.c_int32)),
+              ("seed", C.c_uint64)]
+
+
+def _load():
+  if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "monolith_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; "
+        "g.build()'` or `make -C monolith_amd/csrc`; there is no CPU fallback." % LIB_PATH)
+  lib = C.CDLL(LIB_PATH)
+  lib.mono_last_error.restype = C.c_char_p
+  return lib
+
+
+lib = _load()
+
+
+def check(rc):
+  if rc != 0:
+    raise MonolithHipError((lib.mono_last_error() or b"unknown error").decode())
+
+
+def vp(x):
+  """torch tensor / int / None -> c_void_p."""
+  if x is None:
+    return C.c_void_p(0)
+  if isinstance(x, int):
+    return C.c_void_p(x)
+  return C.c_void_p(x.data_ptr())
+
+
+def stream_ptr(device=None):
+  import torch
+  return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

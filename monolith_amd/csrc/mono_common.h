@@ -1,0 +1,81 @@
+// Shared host/device helpers of libmonolith_hip.so (gfx950 only).
+#ifndef MONO_COMMON_H_
+#define MONO_COMMON_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/monolith_hip.h"
+
+namespace mono {
+
+// ---- error plumbing: no exception crosses the C ABI --------------------------------------
+std::string& last_error_ref();
+int fail(const char* fmt, ...);
+
+#define MONO_HIP(expr)                                                                    \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return ::mono::fail("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,              \
+                          hipGetErrorString(e__));                                        \
+  } while (0)
+
+#define MONO_REQUIRE(cond, ...)                \
+  do {                                         \
+    if (!(cond)) return ::mono::fail(__VA_ARGS__); \
+  } while (0)
+
+#define MONO_TRY(expr)        \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+// ---- hashing (the oracle uses the same functions) ------------------------------------------
+__host__ __device__ inline uint64_t mix64(uint64_t x) {  // splitmix64 finalizer
+  x ^= x >> 30;
+  x *= 0xbf58476d1ce4e5b9ULL;
+  x ^= x >> 27;
+  x *= 0x94d049bb133111ebULL;
+  x ^= x >> 31;
+  return x;
+}
+
+// data/training_instance/cc/reader_util.h:35-37
+__host__ __device__ inline int slot_id_v2(uint64_t fid) { return (int)((fid >> 48) & 0x7FFF); }
+
+// Counter-based stand-in for the reference's thread_local mt19937 uniform initializer
+// (random_uniform_initializer.cc:30-37): distribution parity only.
+__host__ __device__ inline float uniform_init(uint64_t seed, int64_t id, int elem, float lo,
+                                              float hi) {
+  uint64_t h = mix64(seed ^ mix64((uint64_t)id) ^ (0x9e3779b97f4a7c15ULL * (uint64_t)(elem + 1)));
+  float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+  return lo + (hi - lo) * u;
+}
+
+// Grid sizing for memory-bound kernels: enough workgroups to fill 256 CUs several times over,
+// grid-stride the rest (cdna_hip_programming.md Guideline 11).
+inline int grid_for(int64_t work_items, int items_per_block, int max_blocks = 256 * 16) {
+  int64_t b = (work_items + items_per_block - 1) / items_per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+// Growable device scratch owned by a handle. grow() may hipFree + hipMalloc (synchronising
+// the device); steady-state calls do not allocate.
+struct Workspace {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need);
+  void release();
+};
+
+}  // namespace mono
+
+#endif  // MONO_COMMON_H_

@@ -1,0 +1,641 @@
+// ops.hip — routing / exchange / pooling kernels of the hot path for MI355X (gfx950).
+//
+//   F1  fused_reorder_by_indices      ops/fused_reorder_by_indices.cc:36-112
+//   F2  fused_gather_embeddings(+grad) ops/map_id_to_embedding_op.cc:239-343, .cu.cc:30-119
+//   E1  reduce_sum / reduce_mean(+grad) ops/reduce_op.cc:29-180
+//   E2  fused_reduce_sum_and_split(+grad) ops/reduce_op.cc:232-320
+//   E3  fused_sorted_segment_sum      ops/reduce_op.cu.cc:53-161
+//   E4  first_n                       embedding_combiners.py:71-100
+//
+// All of it is HBM-bound integer / row-copy work. Every reduction is deterministic and sums in
+// input order (the reference CPU order): duplicates are grouped with a stable radix sort and a
+// segment is summed left to right, instead of the float atomics of the reference's CUDA kernels.
+#include <algorithm>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <vector>
+
+#include "mono_common.h"
+
+namespace mono {
+
+static Workspace g_ws;       // scratch of the stateless ops (one host thread per GPU)
+static Workspace g_ws_sort;  // radix-sort / scan temporaries
+
+constexpr int kMaxSplit = 64;
+
+static int bits_for_u(uint64_t max_value) {
+  int b = 1;
+  while (b < 64 && (max_value >> b) != 0) ++b;
+  return b;
+}
+
+template <typename K>
+static int sort_pairs_u32(const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n,
+                          int end_bit, hipStream_t st) {
+  size_t tmp = 0;
+  MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, end_bit, st));
+  MONO_TRY(g_ws_sort.ensure(tmp + 256));
+  MONO_HIP(rocprim::radix_sort_pairs(g_ws_sort.ptr, tmp, kin, kout, vin, vout, n, 0, end_bit, st));
+  return 0;
+}
+
+static int exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n, hipStream_t st) {
+  size_t tmp = 0;
+  MONO_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, 0, n, rocprim::plus<int32_t>(), st));
+  MONO_TRY(g_ws_sort.ensure(tmp + 256));
+  MONO_HIP(rocprim::exclusive_scan(g_ws_sort.ptr, tmp, in, out, 0, n, rocprim::plus<int32_t>(), st));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ sortedness
+template <typename K>
+__global__ void __launch_bounds__(256) k_check_sorted(const K* keys, int64_t n, int64_t limit,
+                                                      int* flags) {
+  // flags[0] |= 1 if unsorted, flags[0] |= 2 if a key is outside [0, limit)
+  int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    K k = keys[i];
+    if (i > 0 && keys[i - 1] > k) bad |= 1;
+    if (k < 0 || (int64_t)k >= limit) bad |= 2;
+  }
+  if (bad) atomicOr(flags, bad);
+}
+
+template <typename K>
+static int check_keys(const K* keys, int64_t n, int64_t limit, int* h_flags, hipStream_t st) {
+  MONO_TRY(g_ws.ensure(256));
+  int* flags = (int*)g_ws.ptr;
+  MONO_HIP(hipMemsetAsync(flags, 0, sizeof(int), st));
+  if (n > 0)
+    hipLaunchKernelGGL(k_check_sorted<K>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, keys, n,
+                       limit, flags);
+  MONO_HIP(hipMemcpyAsync(h_flags, flags, sizeof(int), hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_keys_to_u32(const K* in, int64_t n, uint32_t* keys,
+                                                     uint32_t* idx) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    keys[i] = (uint32_t)in[i];
+    idx[i] = (uint32_t)i;
+  }
+}
+
+// A view of row ids that is sorted: either the caller's array (already sorted) or a stable
+// sort of it with the permutation.
+template <typename K>
+struct SortedRows {
+  const K* rows = nullptr;       // valid when perm == nullptr
+  const uint32_t* urows = nullptr;  // valid when perm != nullptr
+  const uint32_t* perm = nullptr;
+};
+
+template <typename K>
+static int make_sorted_rows(const K* row_ids, int64_t n, int64_t batch, SortedRows<K>* out,
+                            const char* who, hipStream_t st) {
+  int flags = 0;
+  MONO_TRY(check_keys<K>(row_ids, n, batch, &flags, st));
+  MONO_REQUIRE(!(flags & 2), "%s: a row id is outside [0, %lld)", who, (long long)batch);
+  if (!(flags & 1)) {
+    out->rows = row_ids;
+    return 0;
+  }
+  MONO_REQUIRE(n < (int64_t)0xFFFFFFF0ll, "%s: too many rows", who);
+  const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
+  MONO_TRY(g_ws.ensure(256 + 4 * n_al * sizeof(uint32_t)));
+  uint32_t* kin = (uint32_t*)((char*)g_ws.ptr + 256);
+  uint32_t* iin = kin + n_al;
+  uint32_t* kout = iin + n_al;
+  uint32_t* iout = kout + n_al;
+  hipLaunchKernelGGL(k_keys_to_u32<K>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, row_ids, n,
+                     kin, iin);
+  MONO_TRY(sort_pairs_u32<uint32_t>(kin, kout, iin, iout, (size_t)n, bits_for_u((uint64_t)batch), st));
+  out->urows = kout;
+  out->perm = iout;
+  return 0;
+}
+
+template <typename T>
+__device__ inline int64_t lower_bound_dev(const T* a, int64_t n, int64_t v) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+struct SplitArgs {
+  int M;
+  int dims[kMaxSplit];
+  float* outs[kMaxSplit];
+};
+
+// E1/E2/E3: out[b, :] = sum over the rows of segment b, left to right. One thread per output
+// element; consecutive threads read consecutive floats of the same value row (coalesced).
+template <typename K, bool MEAN>
+__global__ void __launch_bounds__(256) k_segment_reduce(SortedRows<K> sr, const float* __restrict__ v,
+                                                        int64_t n, int64_t dim, int64_t batch,
+                                                        SplitArgs sp) {
+  const int64_t total = batch * dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / dim, k = e - b * dim;
+    int64_t lo, hi;
+    if (sr.perm) {
+      lo = lower_bound_dev(sr.urows, n, b);
+      hi = lower_bound_dev(sr.urows, n, b + 1);
+    } else {
+      lo = lower_bound_dev(sr.rows, n, b);
+      hi = lower_bound_dev(sr.rows, n, b + 1);
+    }
+    float acc = 0.f;
+    for (int64_t p = lo; p < hi; ++p) {
+      int64_t i = sr.perm ? (int64_t)sr.perm[p] : p;
+      acc += v[i * dim + k];
+    }
+    if (MEAN) {
+      // reduce_op.cc:81: float multiply = 1.0 / static_cast<float>(count)
+      float mul = (float)(1.0 / (double)(float)(uint64_t)(hi - lo));
+      acc *= mul;
+    }
+    int m = 0;
+    int64_t kk = k;
+    while (m + 1 < sp.M && kk >= sp.dims[m]) {
+      kk -= sp.dims[m];
+      ++m;
+    }
+    sp.outs[m][b * sp.dims[m] + kk] = acc;
+  }
+}
+
+// E1 gradients: out[i, :] = grads[row[i], :] (* 1/count(row[i]) for mean); E2 gradient gathers
+// from M split tensors.
+template <typename K, bool MEAN>
+__global__ void __launch_bounds__(256) k_segment_gather(const K* __restrict__ row_ids,
+                                                        SortedRows<K> sr, int64_t n, int64_t dim,
+                                                        SplitArgs sp, float* __restrict__ out) {
+  const int64_t total = n * dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / dim, k = e - i * dim;
+    const int64_t b = (int64_t)row_ids[i];
+    int m = 0;
+    int64_t kk = k;
+    while (m + 1 < sp.M && kk >= sp.dims[m]) {
+      kk -= sp.dims[m];
+      ++m;
+    }
+    float g = sp.outs[m][b * sp.dims[m] + kk];
+    if (MEAN) {
+      int64_t lo, hi;
+      if (sr.perm) {
+        lo = lower_bound_dev(sr.urows, n, b);
+        hi = lower_bound_dev(sr.urows, n, b + 1);
+      } else {
+        lo = lower_bound_dev(sr.rows, n, b);
+        hi = lower_bound_dev(sr.rows, n, b + 1);
+      }
+      g *= (float)(1.0 / (double)(float)(uint64_t)(hi - lo));
+    }
+    out[e] = g;
+  }
+}
+
+// E4: out[b, pos, :] = v[i, :] for the first max_seq rows of each (sorted) segment.
+__global__ void __launch_bounds__(256) k_first_n(const int64_t* __restrict__ row_ids,
+                                                 const float* __restrict__ v, int64_t n, int64_t dim,
+                                                 int64_t max_seq, float* __restrict__ out) {
+  const int64_t total = n * dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / dim, k = e - i * dim;
+    const int64_t b = row_ids[i];
+    const int64_t pos = i - lower_bound_dev(row_ids, n, b);
+    if (pos < max_seq) out[(b * max_seq + pos) * dim + k] = v[e];
+  }
+}
+
+// F2 forward: out[j, k] = fused[off[j] + k].
+__global__ void __launch_bounds__(256) k_gather_rows(const float* __restrict__ fused,
+                                                     const int32_t* __restrict__ off, int64_t len,
+                                                     int dim, float* __restrict__ out) {
+  const int64_t total = len * dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / dim;
+    const int k = (int)(e - j * dim);
+    out[e] = fused[(int64_t)off[j] + k];
+  }
+}
+
+// F2 backward: occurrences sharing an offset are summed in input order by the segment head.
+__global__ void __launch_bounds__(256) k_scatter_rows_sorted(const uint32_t* __restrict__ skey,
+                                                             const uint32_t* __restrict__ sidx,
+                                                             int64_t n, int dim,
+                                                             const float* __restrict__ g,
+                                                             float* __restrict__ out) {
+  const int64_t total = n * dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = e / dim;
+    const int k = (int)(e - j * dim);
+    const uint32_t key = skey[j];
+    if (j > 0 && skey[j - 1] == key) continue;
+    float acc = 0.f;
+    for (int64_t p = j; p < n && skey[p] == key; ++p) acc = g[(int64_t)sidx[p] * dim + k] + acc;
+    out[(int64_t)key + k] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------ F1 reorder
+struct ReorderArgs {
+  int M, N, shard_rule;
+  int64_t total;
+};
+
+struct SlotMeta {  // per merged slot, device array
+  const int64_t* ids;
+  int32_t* out_off;
+  int64_t base;       // first global occurrence index of this slot
+  int64_t len;
+  int64_t hash_base;  // first cell of this slot's dedup region
+  uint64_t hash_mask; // region size - 1 (power of two); cell [hash_base + size] = key -1
+  int32_t dim;
+};
+
+__device__ inline int find_slot_of(const SlotMeta* sm, int M, int64_t gidx) {
+  int lo = 0, hi = M - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (sm[mid].base <= gidx) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__device__ inline int64_t floormod_dev(int64_t a, int64_t b) {
+  int64_t r = a % b;
+  return r < 0 ? r + b : r;
+}
+
+// Pass 1: per-slot dedup set in HBM (open addressing, 64-bit CAS); every cell remembers the
+// smallest global occurrence index that hit it = the first occurrence.
+__global__ void __launch_bounds__(256) k_reorder_insert(ReorderArgs a, const SlotMeta* sm,
+                                                        int64_t* hkeys, uint32_t* hfirst,
+                                                        uint32_t* hcell) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const int m = find_slot_of(sm, a.M, g);
+    const SlotMeta s = sm[m];
+    const int64_t key = s.ids[g - s.base];
+    int64_t cell;
+    if (key == -1) {
+      cell = s.hash_base + (int64_t)s.hash_mask + 1;
+    } else {
+      uint64_t p = mix64((uint64_t)key) & s.hash_mask;
+      for (;;) {
+        int64_t* kp = hkeys + s.hash_base + (int64_t)p;
+        int64_t cur = *kp;
+        if (cur == -1) {
+          cur = (int64_t)atomicCAS(reinterpret_cast<unsigned long long*>(kp),
+                                   (unsigned long long)(-1ll), (unsigned long long)key);
+          if (cur == -1) cur = key;
+        }
+        if (cur == key) break;
+        p = (p + 1) & s.hash_mask;
+      }
+      cell = s.hash_base + (int64_t)p;
+    }
+    hcell[g] = (uint32_t)cell;
+    atomicMin(&hfirst[cell], (uint32_t)g);
+  }
+}
+
+// Pass 2: sort key of every occurrence = shard * M + slot for first occurrences, sentinel N*M
+// for the rest; the stable sort then yields exactly the reference's output order.
+__global__ void __launch_bounds__(256) k_reorder_keys(ReorderArgs a, const SlotMeta* sm,
+                                                      const uint32_t* hfirst, const uint32_t* hcell,
+                                                      uint32_t* skey, uint32_t* sidx) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const int m = find_slot_of(sm, a.M, g);
+    uint32_t key = (uint32_t)(a.N * a.M);
+    if (hfirst[hcell[g]] == (uint32_t)g) {
+      const int64_t id = sm[m].ids[g - sm[m].base];
+      // distribution_ops.py:255-272
+      const int shard = a.shard_rule == 1 ? (int)(1 + floormod_dev(id, a.N - 1))
+                                          : (int)floormod_dev(id, a.N);
+      key = (uint32_t)(shard * a.M + m);
+    }
+    skey[g] = key;
+    sidx[g] = (uint32_t)g;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_reorder_dims(ReorderArgs a, const SlotMeta* sm,
+                                                      const uint32_t* skey, int32_t* dims,
+                                                      int32_t* hist) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.total;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t key = skey[r];
+    const bool uniq = key < (uint32_t)(a.N * a.M);
+    dims[r] = uniq ? sm[key % a.M].dim : 0;
+    if (uniq) atomicAdd(&hist[key], 1);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_reorder_emit(ReorderArgs a, const SlotMeta* sm,
+                                                      const uint32_t* skey, const uint32_t* sidx,
+                                                      const int32_t* emb_off, const uint32_t* hcell,
+                                                      uint32_t* hfirst, int64_t* out_ids) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.total;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t key = skey[r];
+    if (key >= (uint32_t)(a.N * a.M)) continue;
+    const uint32_t g = sidx[r];
+    const SlotMeta& s = sm[key % a.M];
+    out_ids[r] = s.ids[(int64_t)g - s.base];
+    hfirst[hcell[g]] = (uint32_t)emb_off[r];  // the cell now carries the embedding offset
+  }
+}
+
+__global__ void __launch_bounds__(256) k_reorder_offsets(ReorderArgs a, const SlotMeta* sm,
+                                                         const uint32_t* hfirst,
+                                                         const uint32_t* hcell) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const int m = find_slot_of(sm, a.M, g);
+    sm[m].out_off[g - sm[m].base] = (int32_t)hfirst[hcell[g]];
+  }
+}
+
+static SplitArgs single_split(float* out, int64_t dim) {
+  SplitArgs sp{};
+  sp.M = 1;
+  sp.dims[0] = (int)dim;
+  sp.outs[0] = out;
+  return sp;
+}
+
+template <typename K, bool MEAN>
+static int run_reduce(const K* row_ids, const float* values, int64_t n, int64_t dim, int64_t batch,
+                      const SplitArgs& sp, const char* who, hipStream_t st) {
+  MONO_REQUIRE(dim > 0 && batch >= 0 && n >= 0, "%s: bad shape", who);
+  if (batch == 0) return 0;
+  SortedRows<K> sr;
+  MONO_TRY(make_sorted_rows<K>(row_ids, n, batch, &sr, who, st));
+  hipLaunchKernelGGL((k_segment_reduce<K, MEAN>), dim3(grid_for(batch * dim, 256)), dim3(256), 0, st,
+                     sr, values, n, dim, batch, sp);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mono
+
+using namespace mono;
+
+extern "C" {
+
+int mono_reduce_sum(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
+                    int64_t batch, float* out, void* stream) {
+  return run_reduce<int64_t, false>(row_ids, values, n, dim, batch, single_split(out, dim),
+                                    "mono_reduce_sum", (hipStream_t)stream);
+}
+
+int mono_reduce_mean(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
+                     int64_t batch, float* out, void* stream) {
+  return run_reduce<int64_t, true>(row_ids, values, n, dim, batch, single_split(out, dim),
+                                   "mono_reduce_mean", (hipStream_t)stream);
+}
+
+int mono_reduce_sum_gradient(const int64_t* row_ids, const float* grads, int64_t n, int64_t dim,
+                             int64_t batch, float* out, void* stream) {
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int flags = 0;
+  MONO_TRY(check_keys<int64_t>(row_ids, n, batch, &flags, st));
+  MONO_REQUIRE(!(flags & 2), "mono_reduce_sum_gradient: a row id is outside [0, %lld)", (long long)batch);
+  SortedRows<int64_t> sr;
+  hipLaunchKernelGGL((k_segment_gather<int64_t, false>), dim3(grid_for(n * dim, 256)), dim3(256), 0,
+                     st, row_ids, sr, n, dim, single_split(const_cast<float*>(grads), dim), out);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int mono_reduce_mean_gradient(const int64_t* row_ids, const float* grads, int64_t n, int64_t dim,
+                              int64_t batch, float* out, void* stream) {
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  SortedRows<int64_t> sr;
+  MONO_TRY(make_sorted_rows<int64_t>(row_ids, n, batch, &sr, "mono_reduce_mean_gradient", st));
+  hipLaunchKernelGGL((k_segment_gather<int64_t, true>), dim3(grid_for(n * dim, 256)), dim3(256), 0,
+                     st, row_ids, sr, n, dim, single_split(const_cast<float*>(grads), dim), out);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int mono_fused_reduce_sum_and_split(const int64_t* row_ids, const float* values, int64_t n,
+                                    int64_t dim, int64_t batch, const int32_t* h_split_dims, int M,
+                                    float* const* outs, void* stream) {
+  MONO_REQUIRE(M >= 1 && M <= kMaxSplit, "mono_fused_reduce_sum_and_split: %d splits (max %d)", M,
+               kMaxSplit);
+  SplitArgs sp{};
+  sp.M = M;
+  int64_t sum = 0;
+  for (int m = 0; m < M; ++m) {
+    sp.dims[m] = h_split_dims[m];
+    sp.outs[m] = outs[m];
+    sum += h_split_dims[m];
+  }
+  MONO_REQUIRE(sum == dim, "mono_fused_reduce_sum_and_split: sum(split_dims) %lld != dim %lld",
+               (long long)sum, (long long)dim);
+  return run_reduce<int64_t, false>(row_ids, values, n, dim, batch, sp,
+                                    "mono_fused_reduce_sum_and_split", (hipStream_t)stream);
+}
+
+int mono_fused_reduce_sum_and_split_gradient(const int64_t* row_ids, const float* const* grads,
+                                             int64_t n, int64_t batch, const int32_t* h_split_dims,
+                                             int M, float* out, void* stream) {
+  MONO_REQUIRE(M >= 1 && M <= kMaxSplit, "mono_fused_reduce_sum_and_split_gradient: %d splits", M);
+  if (n == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  SplitArgs sp{};
+  sp.M = M;
+  int64_t dim = 0;
+  for (int m = 0; m < M; ++m) {
+    sp.dims[m] = h_split_dims[m];
+    sp.outs[m] = const_cast<float*>(grads[m]);
+    dim += h_split_dims[m];
+  }
+  int flags = 0;
+  MONO_TRY(check_keys<int64_t>(row_ids, n, batch, &flags, st));
+  MONO_REQUIRE(!(flags & 2), "mono_fused_reduce_sum_and_split_gradient: row id out of range");
+  SortedRows<int64_t> sr;
+  hipLaunchKernelGGL((k_segment_gather<int64_t, false>), dim3(grid_for(n * dim, 256)), dim3(256), 0,
+                     st, row_ids, sr, n, dim, sp, out);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int mono_fused_sorted_segment_sum(const int32_t* const* indices, const float* const* values,
+                                  const int64_t* h_lens, const int64_t* h_dims,
+                                  const int64_t* h_out_rows, int N, float* const* outs,
+                                  void* stream) {
+  for (int t = 0; t < N; ++t)
+    MONO_TRY((run_reduce<int32_t, false>(indices[t], values[t], h_lens[t], h_dims[t], h_out_rows[t],
+                                         single_split(outs[t], h_dims[t]),
+                                         "mono_fused_sorted_segment_sum", (hipStream_t)stream)));
+  return 0;
+}
+
+int mono_first_n(const int64_t* row_ids, const float* values, int64_t n, int64_t dim, int64_t batch,
+                 int64_t max_seq, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  MONO_REQUIRE(dim > 0 && max_seq > 0, "mono_first_n: bad shape");
+  MONO_HIP(hipMemsetAsync(out, 0, (size_t)batch * max_seq * dim * sizeof(float), st));
+  if (n == 0) return 0;
+  int flags = 0;
+  MONO_TRY(check_keys<int64_t>(row_ids, n, batch, &flags, st));
+  MONO_REQUIRE(flags == 0, "mono_first_n: row ids must be sorted and inside [0, %lld)", (long long)batch);
+  hipLaunchKernelGGL(k_first_n, dim3(grid_for(n * dim, 256)), dim3(256), 0, st, row_ids, values, n,
+                     dim, max_seq, out);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int mono_fused_gather_embeddings_by_input(const float* fused, int64_t fused_len,
+                                          const int32_t* const* offsets, const int64_t* h_lens,
+                                          const int32_t* h_dims, int M, float* const* outs,
+                                          void* stream) {
+  (void)fused_len;
+  hipStream_t st = (hipStream_t)stream;
+  for (int m = 0; m < M; ++m) {
+    if (h_lens[m] == 0) continue;
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(h_lens[m] * h_dims[m], 256)), dim3(256), 0, st,
+                       fused, offsets[m], h_lens[m], h_dims[m], outs[m]);
+  }
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int mono_fused_gather_embeddings_by_input_gradient(int64_t fused_len, const float* const* grads,
+                                                   const int32_t* const* offsets,
+                                                   const int64_t* h_lens, const int32_t* h_dims,
+                                                   int M, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  MONO_HIP(hipMemsetAsync(out, 0, (size_t)fused_len * sizeof(float), st));
+  for (int m = 0; m < M; ++m) {
+    const int64_t n = h_lens[m];
+    if (n == 0) continue;
+    const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
+    MONO_TRY(g_ws.ensure(256 + 4 * n_al * sizeof(uint32_t)));
+    uint32_t* kin = (uint32_t*)((char*)g_ws.ptr + 256);
+    uint32_t* iin = kin + n_al;
+    uint32_t* kout = iin + n_al;
+    uint32_t* iout = kout + n_al;
+    hipLaunchKernelGGL(k_keys_to_u32<int32_t>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st,
+                       offsets[m], n, kin, iin);
+    MONO_TRY(sort_pairs_u32<uint32_t>(kin, kout, iin, iout, (size_t)n,
+                                      bits_for_u((uint64_t)fused_len), st));
+    hipLaunchKernelGGL(k_scatter_rows_sorted, dim3(grid_for(n * h_dims[m], 256)), dim3(256), 0, st,
+                       kout, iout, n, h_dims[m], grads[m], out);
+    MONO_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h_lens, int M, int N,
+                                  const int32_t* h_dims, int shard_rule, int64_t* out_ids,
+                                  int64_t* h_n_unique, int32_t* h_shard_sizes,
+                                  int32_t* h_sharded_slot_sizes, int32_t* const* out_offsets,
+                                  void* stream) {
+  MONO_REQUIRE(M >= 1 && N >= 1, "mono_fused_reorder_by_indices: M %d N %d", M, N);
+  MONO_REQUIRE(shard_rule == 0 || (shard_rule == 1 && N >= 2),
+               "mono_fused_reorder_by_indices: shard_rule %d with N %d", shard_rule, N);
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < N; ++i) h_shard_sizes[i] = 0;
+  for (int i = 0; i < N * M; ++i) h_sharded_slot_sizes[i] = 0;
+  *h_n_unique = 0;
+  std::vector<SlotMeta> sm(M);
+  int64_t total = 0, cells = 0;
+  for (int m = 0; m < M; ++m) {
+    uint64_t sz = 8;
+    while (sz < (uint64_t)h_lens[m] * 2) sz <<= 1;
+    sm[m].ids = inputs[m];
+    sm[m].out_off = out_offsets[m];
+    sm[m].base = total;
+    sm[m].len = h_lens[m];
+    sm[m].hash_base = cells;
+    sm[m].hash_mask = sz - 1;
+    sm[m].dim = h_dims[m];
+    total += h_lens[m];
+    cells += (int64_t)sz + 1;
+  }
+  if (total == 0) return 0;
+  MONO_REQUIRE(total < (int64_t)0xFFFFFFF0ll && cells < (int64_t)0xFFFFFFF0ll,
+               "mono_fused_reorder_by_indices: too many ids");
+  const size_t t_al = ((size_t)total + 63) & ~(size_t)63;
+  const size_t c_al = ((size_t)cells + 63) & ~(size_t)63;
+  const size_t hist_al = ((size_t)(N * M + 1) + 63) & ~(size_t)63;
+  size_t bytes = 256 + sizeof(SlotMeta) * M + 64;
+  const size_t off_meta = 256;
+  const size_t off_hkeys = (off_meta + sizeof(SlotMeta) * M + 63) & ~(size_t)63;
+  const size_t off_hfirst = off_hkeys + c_al * 8;
+  const size_t off_hcell = off_hfirst + c_al * 4;
+  const size_t off_skey = off_hcell + t_al * 4;
+  const size_t off_sidx = off_skey + t_al * 4;
+  const size_t off_skey2 = off_sidx + t_al * 4;
+  const size_t off_sidx2 = off_skey2 + t_al * 4;
+  const size_t off_dims = off_sidx2 + t_al * 4;
+  const size_t off_scan = off_dims + t_al * 4;
+  const size_t off_hist = off_scan + t_al * 4;
+  bytes = off_hist + hist_al * 4;
+  MONO_TRY(g_ws.ensure(bytes));
+  char* base = (char*)g_ws.ptr;
+  SlotMeta* d_sm = (SlotMeta*)(base + off_meta);
+  int64_t* hkeys = (int64_t*)(base + off_hkeys);
+  uint32_t* hfirst = (uint32_t*)(base + off_hfirst);
+  uint32_t* hcell = (uint32_t*)(base + off_hcell);
+  uint32_t* skey = (uint32_t*)(base + off_skey);
+  uint32_t* sidx = (uint32_t*)(base + off_sidx);
+  uint32_t* skey2 = (uint32_t*)(base + off_skey2);
+  uint32_t* sidx2 = (uint32_t*)(base + off_sidx2);
+  int32_t* dims = (int32_t*)(base + off_dims);
+  int32_t* scan = (int32_t*)(base + off_scan);
+  int32_t* hist = (int32_t*)(base + off_hist);
+  MONO_HIP(hipMemcpyAsync(d_sm, sm.data(), sizeof(SlotMeta) * M, hipMemcpyHostToDevice, st));
+  MONO_HIP(hipMemsetAsync(hkeys, 0xFF, c_al * 8, st));
+  MONO_HIP(hipMemsetAsync(hfirst, 0xFF, c_al * 4, st));
+  MONO_HIP(hipMemsetAsync(hist, 0, hist_al * 4, st));
+  ReorderArgs a{M, N, shard_rule, total};
+  const dim3 grid(grid_for(total, 256)), blk(256);
+  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hkeys, hfirst, hcell);
+  hipLaunchKernelGGL(k_reorder_keys, grid, blk, 0, st, a, d_sm, hfirst, hcell, skey, sidx);
+  MONO_HIP(hipGetLastError());
+  MONO_TRY(sort_pairs_u32<uint32_t>(skey, skey2, sidx, sidx2, (size_t)total,
+                                    bits_for_u((uint64_t)N * M), st));
+  hipLaunchKernelGGL(k_reorder_dims, grid, blk, 0, st, a, d_sm, skey2, dims, hist);
+  MONO_HIP(hipGetLastError());
+  MONO_TRY(exclusive_scan_i32(dims, scan, (size_t)total, st));
+  hipLaunchKernelGGL(k_reorder_emit, grid, blk, 0, st, a, d_sm, skey2, sidx2, scan, hcell, hfirst,
+                     out_ids);
+  hipLaunchKernelGGL(k_reorder_offsets, grid, blk, 0, st, a, d_sm, hfirst, hcell);
+  MONO_HIP(hipGetLastError());
+  MONO_HIP(hipMemcpyAsync(h_sharded_slot_sizes, hist, (size_t)N * M * 4, hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  int64_t uniq = 0;
+  for (int n = 0; n < N; ++n)
+    for (int m = 0; m < M; ++m) {
+      h_shard_sizes[n] += h_sharded_slot_sizes[n * M + m];
+      uniq += h_sharded_slot_sizes[n * M + m];
+    }
+  *h_n_unique = uniq;
+  return 0;
+}
+
+}  // extern "C"

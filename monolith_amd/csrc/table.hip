@@ -1,0 +1,1056 @@
+// table.hip — HBM-resident open-addressing embedding table for MI355X (gfx950).
+//
+// Replaces runtime/hash_table/cuckoohash/* + entry_accessor + optimizer/* + the table half of
+// ops/embedding_hash_table_tf_bridge.cc. Only set semantics of the cuckoo map are observable
+// (SURVEY.md §8a-A2), so placement is ours:
+//
+//   keys  int64[cap]            power-of-two slots, 8-slot (64 B) buckets, linear probing over
+//                               buckets; EMPTY = -1 (hipMemset 0xFF clears), TOMB = -2
+//   rows  float[(cap+2) * R]    slot s -> R = dim + optimizer-state floats, contiguous so one
+//                               update touches one 128 B line at dim 16 + Adagrad
+//   ts    uint32[cap+2]         last update time (entry_defs.h:31-33)
+//   special uint32[2]           presence of the two keys that collide with the sentinels; their
+//                               rows live in slots cap and cap+1, so every int64 is a valid key
+//
+// Execution model: an 8-lane sub-group of a 64-lane wavefront owns one id. The 8 lanes load one
+// bucket (one coalesced 64 B access), vote with a wave ballot, then move the row with the same
+// 8 lanes (coalesced 8/16 B per lane). Inserts claim a slot with a 64-bit atomicCAS.
+// Writers never race on a row: every write path first groups occurrences by slot (stable LSD
+// radix sort of 32-bit slots, or of the 64-bit keys when a hash filter gates inserts) and one
+// sub-group walks a key's occurrences in input order — which is also what makes duplicate
+// handling bit-exact with the reference's sequential loops (SURVEY.md §8a closed forms).
+#include <algorithm>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+#include <vector>
+
+#include "filter_dev.h"
+#include "mono_common.h"
+
+namespace mono {
+
+constexpr int64_t kEmpty = -1;
+constexpr int64_t kTomb = -2;
+constexpr int kBucket = 8;
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+constexpr int kMaxSeg = 8;
+constexpr double kMaxLoad = 0.6;    // rehash when live + tombstones would exceed this
+constexpr double kGrowTarget = 0.3;  // load right after a rehash
+
+enum { MODE_ASSIGN = 0, MODE_ASSIGN_ADD = 1, MODE_OPT_SEQ = 2, MODE_OPT_DEDUP = 3, MODE_IMPORT = 4 };
+enum { OPTK_SGD = 0, OPTK_ADAGRAD = 1, OPTK_FTRL = 2, OPTK_MULTI = 3 };
+
+struct SegDev {
+  int dim, opt_kind, w_off, st_off, init_kind;
+  float init_acc, wd, l1, l2, beta, init_a, init_b;
+};
+
+struct TableDev {  // passed to kernels by value
+  int64_t* keys;
+  uint32_t* ts;
+  float* rows;
+  uint32_t* special;
+  unsigned long long* counters;  // [0] live rows, [1] tombstones, [2] export cursor
+  uint64_t cap;
+  uint64_t bucket_mask;
+  int dim, row_floats, n_seg;
+  int default_expire_days;
+  uint64_t seed;
+  const int32_t* slot_expire;  // int32[32768] or nullptr
+  SegDev seg[kMaxSeg];
+};
+
+struct Table {
+  TableDev d{};
+  std::vector<mono_segment_cfg> segs;
+  int opt_tmpl = OPTK_SGD;  // kernel specialisation
+  int vec = 1;              // floats per lane per access
+  int64_t used_upper = 0;   // host upper bound of live + tombstones
+  int64_t max_update_ts = 0;
+  int32_t* slot_expire_dev = nullptr;
+  Workspace ws;
+};
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+
+__device__ __forceinline__ int lane_sub() { return threadIdx.x & 7; }
+__device__ __forceinline__ int lane_gshift() { return (threadIdx.x & 63) & ~7; }
+__device__ __forceinline__ uint32_t group_bits(bool pred, int gshift) {
+  return (uint32_t)((__ballot(pred) >> gshift) & 0xFFull);
+}
+
+__device__ inline uint32_t group_find(const TableDev& t, int64_t key, int sub, int gshift) {
+  if (key == kEmpty || key == kTomb) {
+    int j = key == kTomb;
+    return t.special[j] ? (uint32_t)(t.cap + j) : kNoSlot;
+  }
+  uint64_t b = mix64((uint64_t)key) & t.bucket_mask;
+  for (uint64_t probes = 0; probes <= t.bucket_mask; ++probes) {
+    int64_t k = t.keys[b * kBucket + sub];
+    uint32_t m = group_bits(k == key, gshift);
+    if (m) return (uint32_t)(b * kBucket + (__ffs(m) - 1));
+    if (group_bits(k == kEmpty, gshift)) return kNoSlot;
+    b = (b + 1) & t.bucket_mask;
+  }
+  return kNoSlot;
+}
+
+// Find `key` or claim the first empty slot of its probe sequence. Slots only go EMPTY -> key
+// inside a launch, a possibly stale bucket image can only show EMPTY where a key already
+// sits, and every believed-EMPTY slot is confirmed by the CAS, so concurrent sub-groups
+// inserting the same key always converge on one slot.
+__device__ inline uint32_t group_find_or_claim(const TableDev& t, int64_t key, int sub, int gshift,
+                                               bool* claimed) {
+  *claimed = false;
+  if (key == kEmpty || key == kTomb) {
+    int j = key == kTomb;
+    bool won = false;
+    if (sub == 0) won = atomicCAS(&t.special[j], 0u, 1u) == 0u;
+    *claimed = group_bits(won, gshift) != 0;
+    return (uint32_t)(t.cap + j);
+  }
+  uint64_t b = mix64((uint64_t)key) & t.bucket_mask;
+  for (uint64_t probes = 0; probes <= t.bucket_mask; ++probes) {
+    int64_t k = t.keys[b * kBucket + sub];
+    for (;;) {
+      uint32_t m = group_bits(k == key, gshift);
+      if (m) return (uint32_t)(b * kBucket + (__ffs(m) - 1));
+      uint32_t e = group_bits(k == kEmpty, gshift);
+      if (!e) break;
+      int pos = __ffs(e) - 1;
+      bool won = false;
+      if (sub == pos) {
+        unsigned long long old =
+            atomicCAS(reinterpret_cast<unsigned long long*>(&t.keys[b * kBucket + pos]),
+                      (unsigned long long)kEmpty, (unsigned long long)key);
+        won = (int64_t)old == kEmpty;
+        k = won ? key : (int64_t)old;
+      }
+      if (group_bits(won, gshift)) {
+        *claimed = true;
+        return (uint32_t)(b * kBucket + pos);
+      }
+    }
+    b = (b + 1) & t.bucket_mask;
+  }
+  return kNoSlot;  // table full: the host-side load bound makes this unreachable
+}
+
+// entry_accessor.cc:139-143: initializer for the weights, optimizer Init for the state.
+__device__ inline float row_init_value(const TableDev& t, int64_t key, int e) {
+  if (e < t.dim) {
+    for (int s = 0; s < t.n_seg; ++s) {
+      const SegDev& c = t.seg[s];
+      if (e >= c.w_off && e < c.w_off + c.dim) {
+        switch (c.init_kind) {
+          case MONO_INIT_ZEROS: return 0.f;
+          case MONO_INIT_ONES: return 1.f;
+          case MONO_INIT_CONSTANT: return c.init_a;
+          default: return uniform_init(t.seed, key, e, c.init_a, c.init_b);
+        }
+      }
+    }
+    return 0.f;
+  }
+  for (int s = 0; s < t.n_seg; ++s) {
+    const SegDev& c = t.seg[s];
+    int len = c.opt_kind == MONO_OPT_ADAGRAD ? c.dim : c.opt_kind == MONO_OPT_FTRL ? 2 * c.dim : 0;
+    if (e >= c.st_off && e < c.st_off + len) return (e - c.st_off < c.dim) ? c.init_acc : 0.f;
+  }
+  return 0.f;
+}
+
+__device__ inline void group_init_row(const TableDev& t, int64_t key, uint32_t slot, int sub) {
+  float* row = t.rows + (uint64_t)slot * t.row_floats;
+  for (int e = sub; e < t.row_floats; e += 8) row[e] = row_init_value(t, key, e);
+}
+
+__device__ inline int expire_days(const TableDev& t, int64_t key) {
+  return t.slot_expire ? t.slot_expire[slot_id_v2((uint64_t)key)] : t.default_expire_days;
+}
+// cuckoo_embedding_hash_table.cc:230
+__device__ inline bool is_expired(const TableDev& t, int64_t key, uint32_t ts, int64_t now) {
+  return now - (int64_t)ts >= (int64_t)expire_days(t, key) * 86400;
+}
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<1> { using T = float; };
+template <>
+struct Vec<2> { using T = float2; };
+template <>
+struct Vec<4> { using T = float4; };
+
+template <int V>
+__device__ __forceinline__ void vload(float (&r)[V], const float* p) {
+  typename Vec<V>::T v = *reinterpret_cast<const typename Vec<V>::T*>(p);
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int i = 0; i < V; ++i) r[i] = f[i];
+}
+template <int V>
+__device__ __forceinline__ void vstore(float* p, const float (&r)[V]) {
+  typename Vec<V>::T v;
+  float* f = reinterpret_cast<float*>(&v);
+#pragma unroll
+  for (int i = 0; i < V; ++i) f[i] = r[i];
+  *reinterpret_cast<typename Vec<V>::T*>(p) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+
+// B1: ops/hash_table_lookup_op.cc:36-73 -> cuckoo_embedding_hash_table.cc:151-160.
+template <int V>
+__global__ void __launch_bounds__(256) k_lookup(TableDev t, const int64_t* __restrict__ ids,
+                                                int64_t n, float* __restrict__ out) {
+  const int sub = lane_sub(), gshift = lane_gshift();
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
+  const int D = t.dim;
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8; i < n; i += ngroups) {
+    int64_t key = ids[i];
+    uint32_t slot = group_find(t, key, sub, gshift);
+    float* dst = out + i * D;
+    const float* src = t.rows + (uint64_t)slot * t.row_floats;
+    for (int e = sub * V; e < D; e += 8 * V) {
+      float r[V];
+      if (slot != kNoSlot) {
+        vload<V>(r, src + e);
+      } else {
+#pragma unroll
+        for (int q = 0; q < V; ++q) r[q] = 0.f;
+      }
+      vstore<V>(dst + e, r);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_contains(TableDev t, const int64_t* __restrict__ ids,
+                                                  int64_t n, uint8_t* __restrict__ out) {
+  const int sub = lane_sub(), gshift = lane_gshift();
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8; i < n; i += ngroups) {
+    uint32_t slot = group_find(t, ids[i], sub, gshift);
+    if (sub == 0) out[i] = slot != kNoSlot;
+  }
+}
+
+// Write path, step 1 (no filter): resolve every occurrence to its slot, inserting + initialising
+// missing keys (cuckoo_embedding_hash_table.cc:284-291). Emits (slot, occurrence index) pairs.
+__global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t* __restrict__ ids,
+                                                       int64_t n, uint32_t* __restrict__ slot_out,
+                                                       uint32_t* __restrict__ idx_out) {
+  const int sub = lane_sub(), gshift = lane_gshift();
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8; i < n; i += ngroups) {
+    int64_t key = ids[i];
+    bool claimed;
+    uint32_t slot = group_find_or_claim(t, key, sub, gshift, &claimed);
+    if (claimed) {
+      group_init_row(t, key, slot, sub);
+      if (sub == 0) {
+        t.ts[slot] = 0;
+        atomicAdd(&t.counters[0], 1ull);
+      }
+    }
+    if (sub == 0) {
+      slot_out[i] = slot;
+      idx_out[i] = (uint32_t)i;
+    }
+  }
+}
+
+__global__ void k_iota(uint32_t* idx, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    idx[i] = (uint32_t)i;
+}
+
+struct ApplyArgs {
+  const void* skeys;     // sorted uint32 slots, or sorted int64 keys when from_keys
+  const uint32_t* sidx;  // occurrence index of each sorted position
+  int64_t n;
+  const float* src;  // grads / values, row-major [*, dim] (MODE_IMPORT: [*, row_floats])
+  const uint32_t* src_ts;  // MODE_IMPORT only
+  int mode;
+  int from_keys;
+  uint32_t ts;
+  float lr[kMaxSeg];
+  FilterDev filt;  // from_keys only; filt.kind == 0 -> no gate
+  int assign_add_semantics;  // filter gate of the per-id AssignAdd loop (bridge :186-209)
+};
+
+template <typename K>
+__device__ inline int64_t segment_end(const K* keys, int64_t j, int64_t n, K key) {
+  // galloping upper bound: first position > j whose key differs
+  int64_t step = 1, lo = j, hi = j + 1;
+  while (hi < n && keys[hi] == key) {
+    lo = hi;
+    step <<= 1;
+    hi = j + step;
+  }
+  if (hi > n) hi = n;
+  // invariant: keys[lo] == key, (hi == n or keys[hi] != key)
+  while (hi - lo > 1) {
+    int64_t mid = lo + ((hi - lo) >> 1);
+    if (keys[mid] == key) lo = mid; else hi = mid;
+  }
+  return hi;
+}
+
+// One optimizer step on one element. Non-contracted arithmetic
+// (-ffp-contract=off) with correctly rounded sqrt/div, i.e. the reference's baseline form.
+__device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, float g, float& w,
+                                         float& s0, float& s1) {
+  if (kind == MONO_OPT_SGD) {  // sgd_optimizer.cc:36-44
+    w -= lr * g;
+  } else if (kind == MONO_OPT_ADAGRAD) {  // avx_utils.h:29-38
+    float gg = g + c.wd * w;
+    s0 += gg * gg;
+    float eff = __fdiv_rn(lr, sqrtf(s0));
+    w -= eff * gg;
+  } else {  // ftrl_optimizer.cc:49-72; s0 = norm, s1 = zero
+    float norm_new = s0 + g * g;
+    float sigma = __fdiv_rn(sqrtf(norm_new) - sqrtf(s0), lr);
+    s1 += (g - sigma * w);
+    s0 = norm_new;
+    float sign = (float)(__float_as_uint(s1) >> 31);  // std::signbit as 0/1
+    w = (fabsf(s1) > c.l1)
+            ? __fdiv_rn(lr * (sign * c.l1 - s1), (sqrtf(s0) + c.beta + c.l2 * lr))
+            : 0.0f;
+  }
+}
+
+// Write path, step 2: one 8-lane sub-group per distinct key walks that key's occurrences in
+// input order (the sort is stable) with the row chunk held in registers, then stores row + ts.
+// B3/B4: bridge :156-313, cuckoo_embedding_hash_table.cc:174-216, entry_accessor.cc:149-171.
+template <int V, int OPTK>
+__global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
+  const int sub = lane_sub(), gshift = lane_gshift();
+  const int64_t j = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
+  if (j >= a.n) return;
+  const int D = t.dim, R = t.row_floats;
+
+  uint32_t slot;
+  int64_t end;
+  int64_t first = j;  // first occurrence (sorted position) that is applied
+  bool fresh = false; // row claimed here and not yet initialised in memory
+  int64_t key = 0;
+  if (!a.from_keys) {
+    const uint32_t* sk = static_cast<const uint32_t*>(a.skeys);
+    slot = sk[j];
+    if (j > 0 && sk[j - 1] == slot) return;
+    if (slot == kNoSlot) return;
+    end = segment_end<uint32_t>(sk, j, a.n, slot);
+  } else {
+    const int64_t* sk = static_cast<const int64_t*>(a.skeys);
+    key = sk[j];
+    if (j > 0 && sk[j - 1] == key) return;
+    end = segment_end<int64_t>(sk, j, a.n, key);
+    slot = group_find(t, key, sub, gshift);
+    if (slot == kNoSlot) {
+      // Unknown id: the hash-filter gate (bridge :167-176, :195-198, :274-277, :288-291).
+      int64_t k = end - j;
+      int64_t skip = 0;
+      if (a.filt.kind != 0) {
+        int thr = filter_threshold(a.filt, key);
+        if (thr > 0) {
+          uint32_t c = 0;
+          if (a.mode == MODE_OPT_DEDUP) {
+            // one add(fid, k); admitted iff old count >= threshold
+            if (sub == 0) c = filter_add(a.filt, (uint64_t)key, (uint32_t)min((int64_t)15, k));
+            c = __shfl(c, 0, 8);
+            skip = c >= (uint32_t)thr ? 0 : k;
+          } else {
+            // occurrence q sees old count min(15, c + q): first admitted q* = max(0, thr - c).
+            // AssignAdd stops counting once the id is inserted; Assign / Optimize count all k.
+            int64_t q;
+            if (sub == 0) {
+              c = filter_get(a.filt, (uint64_t)key);
+              q = (int64_t)thr - (int64_t)c;
+              if (q < 0) q = 0;
+              if (thr > 15) q = k;  // counts saturate at 15: never admitted
+              int64_t adds = a.assign_add_semantics ? (q < k ? q + 1 : k) : k;
+              if (adds > 0) filter_add(a.filt, (uint64_t)key, (uint32_t)min((int64_t)15, adds));
+              c = (uint32_t)(q < k ? q : k);
+            }
+            c = __shfl(c, 0, 8);
+            skip = c;
+          }
+        }
+      }
+      if (skip >= k) return;
+      first = j + skip;
+      bool claimed;
+      slot = group_find_or_claim(t, key, sub, gshift, &claimed);
+      fresh = claimed;
+      if (claimed && sub == 0) atomicAdd(&t.counters[0], 1ull);
+    }
+  }
+
+  float* row = t.rows + (uint64_t)slot * R;
+  if (a.mode == MODE_IMPORT) {  // full-row restore: last occurrence wins
+    uint32_t src_i = a.sidx[end - 1];
+    for (int e = sub; e < R; e += 8) row[e] = a.src[(uint64_t)src_i * R + e];
+    if (sub == 0) t.ts[slot] = a.src_ts[src_i];
+    return;
+  }
+
+  for (int c0 = 0; c0 < D; c0 += 8 * V) {
+    const int e0 = c0 + sub * V;
+    if (e0 >= D) continue;
+    float w[V], s0[V], s1[V];
+    int kind[V];
+    int segi[V];
+    int st0_off[V], st1_off[V];
+    // --- locate state + load
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      if (OPTK == OPTK_MULTI) {
+        int e = e0 + q, s = 0;
+        for (int z = 0; z < t.n_seg; ++z)
+          if (e >= t.seg[z].w_off && e < t.seg[z].w_off + t.seg[z].dim) s = z;
+        segi[q] = s;
+        kind[q] = t.seg[s].opt_kind;
+        st0_off[q] = t.seg[s].st_off + (e - t.seg[s].w_off);
+        st1_off[q] = st0_off[q] + t.seg[s].dim;
+      } else {
+        segi[q] = 0;
+        kind[q] = OPTK;
+        st0_off[q] = D + e0 + q;
+        st1_off[q] = 2 * D + e0 + q;
+      }
+    }
+    const bool need_state = a.mode >= MODE_OPT_SEQ;
+    if (fresh) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        w[q] = row_init_value(t, key, e0 + q);
+        s0[q] = kind[q] != MONO_OPT_SGD ? row_init_value(t, key, st0_off[q]) : 0.f;
+        s1[q] = kind[q] == MONO_OPT_FTRL ? row_init_value(t, key, st1_off[q]) : 0.f;
+      }
+    } else {
+      vload<V>(w, row + e0);
+      if (need_state) {
+        if (OPTK == OPTK_ADAGRAD || OPTK == OPTK_FTRL) vload<V>(s0, row + D + e0);
+        if (OPTK == OPTK_FTRL) vload<V>(s1, row + 2 * D + e0);
+        if (OPTK == OPTK_MULTI) {
+#pragma unroll
+          for (int q = 0; q < V; ++q) {
+            s0[q] = kind[q] != MONO_OPT_SGD ? row[st0_off[q]] : 0.f;
+            s1[q] = kind[q] == MONO_OPT_FTRL ? row[st1_off[q]] : 0.f;
+          }
+        }
+      }
+    }
+    // --- walk the occurrences in input order
+    if (a.mode == MODE_ASSIGN) {
+      vload<V>(w, a.src + (uint64_t)a.sidx[end - 1] * D + e0);
+    } else if (a.mode == MODE_ASSIGN_ADD) {
+      for (int64_t p = first; p < end; ++p) {
+        float g[V];
+        vload<V>(g, a.src + (uint64_t)a.sidx[p] * D + e0);
+#pragma unroll
+        for (int q = 0; q < V; ++q) w[q] += g[q];
+      }
+    } else if (a.mode == MODE_OPT_SEQ) {
+      for (int64_t p = first; p < end; ++p) {
+        float g[V];
+        vload<V>(g, a.src + (uint64_t)a.sidx[p] * D + e0);
+#pragma unroll
+        for (int q = 0; q < V; ++q)
+          opt_step(kind[q], t.seg[segi[q]], a.lr[segi[q]], g[q], w[q], s0[q], s1[q]);
+      }
+    } else {  // MODE_OPT_DEDUP: in-order sum (bridge :251-266), then one step
+      float acc[V];
+      vload<V>(acc, a.src + (uint64_t)a.sidx[first] * D + e0);
+      int64_t p = first + 1;
+      for (; p + 4 <= end; p += 4) {  // 4 independent loads in flight, adds stay in order
+        float g0[V], g1[V], g2[V], g3[V];
+        vload<V>(g0, a.src + (uint64_t)a.sidx[p] * D + e0);
+        vload<V>(g1, a.src + (uint64_t)a.sidx[p + 1] * D + e0);
+        vload<V>(g2, a.src + (uint64_t)a.sidx[p + 2] * D + e0);
+        vload<V>(g3, a.src + (uint64_t)a.sidx[p + 3] * D + e0);
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[q] = (((acc[q] + g0[q]) + g1[q]) + g2[q]) + g3[q];
+      }
+      for (; p < end; ++p) {
+        float g[V];
+        vload<V>(g, a.src + (uint64_t)a.sidx[p] * D + e0);
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[q] = acc[q] + g[q];
+      }
+#pragma unroll
+      for (int q = 0; q < V; ++q)
+        opt_step(kind[q], t.seg[segi[q]], a.lr[segi[q]], acc[q], w[q], s0[q], s1[q]);
+    }
+    // --- store
+    vstore<V>(row + e0, w);
+    if (need_state || fresh) {
+      if (OPTK == OPTK_ADAGRAD || OPTK == OPTK_FTRL) vstore<V>(row + D + e0, s0);
+      if (OPTK == OPTK_FTRL) vstore<V>(row + 2 * D + e0, s1);
+      if (OPTK == OPTK_MULTI) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          if (kind[q] != MONO_OPT_SGD) row[st0_off[q]] = s0[q];
+          if (kind[q] == MONO_OPT_FTRL) row[st1_off[q]] = s1[q];
+        }
+      }
+    }
+  }
+  if (sub == 0) t.ts[slot] = a.ts;
+}
+
+// D1: cuckoo_embedding_hash_table.cc:220-233. One thread per slot, 12 B (key + ts) per slot.
+__global__ void __launch_bounds__(256) k_evict(TableDev t, int64_t now) {
+  const int64_t total = (int64_t)t.cap + 2;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+       s += (int64_t)gridDim.x * blockDim.x) {
+    const bool special = s >= (int64_t)t.cap;
+    int64_t key;
+    bool live;
+    if (!special) {
+      key = t.keys[s];
+      live = key != kEmpty && key != kTomb;
+    } else {
+      key = s == (int64_t)t.cap ? kEmpty : kTomb;
+      live = t.special[s - t.cap] != 0;
+    }
+    const bool dead = live && is_expired(t, key, t.ts[s], now);
+    if (dead) {
+      if (!special) t.keys[s] = kTomb; else t.special[s - t.cap] = 0;
+    }
+    // one pair of counter updates per wave
+    const unsigned long long active = __ballot(true);
+    const unsigned long long m = __ballot(dead);
+    const unsigned long long ms = __ballot(dead && special);
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)active) - 1 && m) {
+      atomicAdd(&t.counters[0], (unsigned long long)(-(long long)__popcll(m)));
+      atomicAdd(&t.counters[1], (unsigned long long)(__popcll(m) - __popcll(ms)));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_export(TableDev t, int64_t max_rows, int apply_expiry,
+                                                int64_t now, int64_t* ids, float* rows,
+                                                uint32_t* ts) {
+  const int64_t total = (int64_t)t.cap + 2;
+  const int R = t.row_floats;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
+       s += (int64_t)gridDim.x * blockDim.x) {
+    int64_t key;
+    bool live;
+    if (s < (int64_t)t.cap) {
+      key = t.keys[s];
+      live = key != kEmpty && key != kTomb;
+    } else {
+      key = s == (int64_t)t.cap ? kEmpty : kTomb;
+      live = t.special[s - t.cap] != 0;
+    }
+    if (live && apply_expiry && is_expired(t, key, t.ts[s], now)) live = false;
+    // wave-aggregated cursor: one atomic per wave
+    const unsigned long long active = __ballot(true);
+    const unsigned long long m = __ballot(live);
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)active) - 1;
+    unsigned long long base = 0;
+    if (lane == leader && m) base = atomicAdd(&t.counters[2], (unsigned long long)__popcll(m));
+    base = __shfl(base, leader);
+    if (live) {
+      unsigned long long pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if ((int64_t)pos < max_rows) {
+        ids[pos] = key;
+        ts[pos] = t.ts[s];
+        for (int e = 0; e < R; ++e) rows[pos * R + e] = t.rows[(uint64_t)s * R + e];
+      }
+    }
+  }
+}
+
+// Re-insert every live row of `o` into the (empty) table `nw`: one sub-group per old bucket.
+__global__ void __launch_bounds__(256) k_rehash(TableDev o, TableDev nw) {
+  const int sub = lane_sub(), gshift = lane_gshift();
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
+  const int64_t nb = (int64_t)o.bucket_mask + 1;
+  const int R = o.row_floats;
+  for (int64_t b = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8; b < nb; b += ngroups) {
+    int64_t k = o.keys[b * kBucket + sub];
+    uint32_t m = group_bits(k != kEmpty && k != kTomb, gshift);
+    while (m) {
+      int p = __ffs(m) - 1;
+      m &= m - 1;
+      int64_t key = __shfl(k, p, 8);
+      bool claimed;
+      uint32_t ns = group_find_or_claim(nw, key, sub, gshift, &claimed);
+      const float* src = o.rows + (uint64_t)(b * kBucket + p) * R;
+      float* dst = nw.rows + (uint64_t)ns * R;
+      for (int e = sub; e < R; e += 8) dst[e] = src[e];
+      if (sub == 0) nw.ts[ns] = o.ts[b * kBucket + p];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+
+static uint64_t pow2_at_least(uint64_t x) {
+  uint64_t p = 1024;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+static int alloc_arrays(TableDev* d, uint64_t cap) {
+  d->cap = cap;
+  d->bucket_mask = cap / kBucket - 1;
+  MONO_HIP(hipMalloc((void**)&d->keys, cap * sizeof(int64_t)));
+  MONO_HIP(hipMalloc((void**)&d->ts, (cap + 2) * sizeof(uint32_t)));
+  MONO_HIP(hipMalloc((void**)&d->rows, (cap + 2) * (uint64_t)d->row_floats * sizeof(float)));
+  MONO_HIP(hipMalloc((void**)&d->special, 2 * sizeof(uint32_t)));
+  MONO_HIP(hipMalloc((void**)&d->counters, 4 * sizeof(unsigned long long)));
+  return 0;
+}
+
+static void free_arrays(TableDev* d) {
+  if (d->keys) (void)hipFree(d->keys);
+  if (d->ts) (void)hipFree(d->ts);
+  if (d->rows) (void)hipFree(d->rows);
+  if (d->special) (void)hipFree(d->special);
+  if (d->counters) (void)hipFree(d->counters);
+  d->keys = nullptr; d->ts = nullptr; d->rows = nullptr; d->special = nullptr; d->counters = nullptr;
+}
+
+static int reset_arrays(TableDev* d, hipStream_t st) {
+  MONO_HIP(hipMemsetAsync(d->keys, 0xFF, d->cap * sizeof(int64_t), st));
+  MONO_HIP(hipMemsetAsync(d->special, 0, 2 * sizeof(uint32_t), st));
+  MONO_HIP(hipMemsetAsync(d->counters, 0, 4 * sizeof(unsigned long long), st));
+  return 0;
+}
+
+static int read_counters(Table* t, hipStream_t st, int64_t* live, int64_t* tombs) {
+  unsigned long long h[2];
+  MONO_HIP(hipMemcpyAsync(h, t->d.counters, sizeof(h), hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  *live = (int64_t)h[0];
+  *tombs = (int64_t)h[1];
+  return 0;
+}
+
+// Rehash into a table of `new_cap` slots (drops tombstones). Peak memory = old + new arrays.
+static int rehash(Table* t, uint64_t new_cap, hipStream_t st) {
+  TableDev nw = t->d;
+  nw.keys = nullptr; nw.ts = nullptr; nw.rows = nullptr; nw.special = nullptr; nw.counters = nullptr;
+  MONO_TRY(alloc_arrays(&nw, new_cap));
+  MONO_TRY(reset_arrays(&nw, st));
+  const int64_t nb = (int64_t)t->d.bucket_mask + 1;
+  hipLaunchKernelGGL(k_rehash, dim3(grid_for(nb, 32)), dim3(256), 0, st, t->d, nw);
+  MONO_HIP(hipGetLastError());
+  const size_t R = t->d.row_floats;
+  MONO_HIP(hipMemcpyAsync(nw.rows + nw.cap * R, t->d.rows + t->d.cap * R, 2 * R * sizeof(float),
+                          hipMemcpyDeviceToDevice, st));
+  MONO_HIP(hipMemcpyAsync(nw.ts + nw.cap, t->d.ts + t->d.cap, 2 * sizeof(uint32_t),
+                          hipMemcpyDeviceToDevice, st));
+  MONO_HIP(hipMemcpyAsync(nw.special, t->d.special, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  MONO_HIP(hipMemcpyAsync(nw.counters, t->d.counters, sizeof(unsigned long long),
+                          hipMemcpyDeviceToDevice, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  free_arrays(&t->d);
+  t->d = nw;
+  return 0;
+}
+
+// Called before any launch that can insert up to `incoming` new keys.
+static int ensure_room(Table* t, int64_t incoming, hipStream_t st) {
+  const int64_t limit = (int64_t)(kMaxLoad * (double)t->d.cap);
+  if (t->used_upper + incoming <= limit) {
+    t->used_upper += incoming;
+    return 0;
+  }
+  int64_t live, tombs;
+  MONO_TRY(read_counters(t, st, &live, &tombs));
+  if (live + tombs + incoming > limit) {
+    uint64_t want = pow2_at_least((uint64_t)((double)(live + incoming) / kGrowTarget) + 1);
+    MONO_TRY(rehash(t, want, st));
+    tombs = 0;
+  }
+  t->used_upper = live + tombs + incoming;
+  return 0;
+}
+
+template <int V>
+static void launch_lookup(const Table* t, const int64_t* ids, int64_t n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_lookup<V>, dim3(grid_for(n, 32)), dim3(256), 0, st, t->d, ids, n, out);
+}
+
+template <int V, int OPTK>
+static void launch_apply_vo(const Table* t, const ApplyArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL((k_apply<V, OPTK>), dim3((unsigned)((a.n + 31) / 32)), dim3(256), 0, st, t->d, a);
+}
+template <int V>
+static void launch_apply_v(const Table* t, const ApplyArgs& a, hipStream_t st) {
+  switch (t->opt_tmpl) {
+    case OPTK_SGD: launch_apply_vo<V, OPTK_SGD>(t, a, st); break;
+    case OPTK_ADAGRAD: launch_apply_vo<V, OPTK_ADAGRAD>(t, a, st); break;
+    case OPTK_FTRL: launch_apply_vo<V, OPTK_FTRL>(t, a, st); break;
+    default: launch_apply_vo<1, OPTK_MULTI>(t, a, st); break;
+  }
+}
+static void launch_apply(const Table* t, const ApplyArgs& a, hipStream_t st) {
+  if (t->opt_tmpl == OPTK_MULTI || t->vec == 1) launch_apply_v<1>(t, a, st);
+  else if (t->vec == 2) launch_apply_v<2>(t, a, st);
+  else launch_apply_v<4>(t, a, st);
+}
+
+static int bits_for(uint64_t max_value) {
+  int b = 1;
+  while (b < 64 && (max_value >> b) != 0) ++b;
+  return b;
+}
+
+// The whole write path. `filter` gates inserts of unknown ids (nullptr / dummy = no gate).
+static int write_path(Table* t, void* filter, const int64_t* ids, const float* src,
+                      const uint32_t* src_ts, int64_t n, int mode, const float* lrs, int n_lrs,
+                      int64_t req_time, int assign_add_semantics, hipStream_t st) {
+  if (n == 0) return 0;
+  MONO_REQUIRE(n < (int64_t)0xFFFFFFF0ll, "batch of %lld ids exceeds the 32-bit index range",
+               (long long)n);
+  MONO_TRY(ensure_room(t, n, st));
+  FilterDev fd{};
+  if (filter) MONO_TRY(filter_dev_view(filter, &fd, st));
+  const bool from_keys = fd.kind != 0;
+
+  ApplyArgs a{};
+  a.n = n;
+  a.src = src;
+  a.src_ts = src_ts;
+  a.mode = mode;
+  a.from_keys = from_keys;
+  a.ts = (uint32_t)req_time;
+  a.filt = fd;
+  a.assign_add_semantics = assign_add_semantics;
+  for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
+
+  const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
+  if (!from_keys) {
+    // (slot, idx) pairs -> stable radix sort on the bits a slot can occupy
+    size_t tmp_bytes = 0;
+    const int end_bit = bits_for(t->d.cap + 1);
+    MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0,
+                                       end_bit, st));
+    tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
+    MONO_TRY(t->ws.ensure(4 * n_al * sizeof(uint32_t) + tmp_bytes));
+    uint32_t* slot_in = (uint32_t*)t->ws.ptr;
+    uint32_t* idx_in = slot_in + n_al;
+    uint32_t* slot_out = idx_in + n_al;
+    uint32_t* idx_out = slot_out + n_al;
+    void* tmp = idx_out + n_al;
+    hipLaunchKernelGGL(k_find_or_claim, dim3(grid_for(n, 32)), dim3(256), 0, st, t->d, ids, n,
+                       slot_in, idx_in);
+    MONO_HIP(hipGetLastError());
+    MONO_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, slot_in, slot_out, idx_in, idx_out,
+                                       (size_t)n, 0, end_bit, st));
+    a.skeys = slot_out;
+    a.sidx = idx_out;
+  } else {
+    size_t tmp_bytes = 0;
+    MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (int64_t*)nullptr, (int64_t*)nullptr,
+                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 64, st));
+    tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
+    MONO_TRY(t->ws.ensure(n_al * sizeof(int64_t) + 2 * n_al * sizeof(uint32_t) + tmp_bytes));
+    int64_t* key_out = (int64_t*)t->ws.ptr;
+    uint32_t* idx_in = (uint32_t*)(key_out + n_al);
+    uint32_t* idx_out = idx_in + n_al;
+    void* tmp = idx_out + n_al;
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 256)), dim3(256), 0, st, idx_in, n);
+    MONO_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, ids, key_out, idx_in, idx_out, (size_t)n, 0,
+                                       64, st));
+    a.skeys = key_out;
+    a.sidx = idx_out;
+  }
+  launch_apply(t, a, st);
+  MONO_HIP(hipGetLastError());
+  if (from_keys) MONO_TRY(filter_after_batch(filter, st));
+  return 0;
+}
+
+}  // namespace mono
+
+using namespace mono;
+
+extern "C" {
+
+int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
+  MONO_REQUIRE(cfg && out_table, "mono_table_create: null argument");
+  MONO_REQUIRE(cfg->n_segments >= 1 && cfg->n_segments <= kMaxSeg,
+               "mono_table_create: %d segments (supported: 1..%d)", cfg->n_segments, kMaxSeg);
+  Table* t = new Table();
+  int w = 0;
+  for (int s = 0; s < cfg->n_segments; ++s) {
+    const mono_segment_cfg& c = cfg->segments[s];
+    if (c.dim <= 0 || c.opt_kind < 0 || c.opt_kind > MONO_OPT_FTRL || c.init_kind < 0 ||
+        c.init_kind > MONO_INIT_UNIFORM) {
+      delete t;
+      return fail("mono_table_create: bad segment %d (dim %d opt %d init %d)", s, c.dim,
+                  c.opt_kind, c.init_kind);
+    }
+    t->segs.push_back(c);
+    w += c.dim;
+  }
+  TableDev& d = t->d;
+  d.dim = w;
+  d.n_seg = cfg->n_segments;
+  int st = w, wo = 0;
+  for (int s = 0; s < cfg->n_segments; ++s) {
+    const mono_segment_cfg& c = cfg->segments[s];
+    SegDev& sd = d.seg[s];
+    sd.dim = c.dim; sd.opt_kind = c.opt_kind; sd.w_off = wo; sd.st_off = st;
+    sd.init_kind = c.init_kind; sd.init_acc = c.init_acc; sd.wd = c.weight_decay;
+    sd.l1 = c.l1; sd.l2 = c.l2; sd.beta = c.beta; sd.init_a = c.init_a; sd.init_b = c.init_b;
+    wo += c.dim;
+    st += c.opt_kind == MONO_OPT_ADAGRAD ? c.dim : c.opt_kind == MONO_OPT_FTRL ? 2 * c.dim : 0;
+  }
+  d.row_floats = st;
+  d.seed = cfg->seed;
+  d.default_expire_days = cfg->default_expire_days;
+  t->opt_tmpl = cfg->n_segments == 1 ? cfg->segments[0].opt_kind : OPTK_MULTI;
+  t->vec = (cfg->n_segments == 1) ? (w % 4 == 0 ? 4 : w % 2 == 0 ? 2 : 1) : 1;
+  if (cfg->n_slot_expire > 0) {
+    std::vector<int32_t> tbl(1 << 15, cfg->default_expire_days);
+    for (int i = 0; i < cfg->n_slot_expire; ++i)
+      if (cfg->slot_ids[i] >= 0 && cfg->slot_ids[i] < (1 << 15))
+        tbl[cfg->slot_ids[i]] = cfg->slot_expire_days[i];
+    if (hipMalloc((void**)&t->slot_expire_dev, tbl.size() * sizeof(int32_t)) != hipSuccess ||
+        hipMemcpy(t->slot_expire_dev, tbl.data(), tbl.size() * sizeof(int32_t),
+                  hipMemcpyHostToDevice) != hipSuccess) {
+      delete t;
+      return fail("mono_table_create: cannot allocate the slot-expire table");
+    }
+    d.slot_expire = t->slot_expire_dev;
+  }
+  int64_t want_rows = cfg->initial_capacity > 0 ? cfg->initial_capacity : 1;
+  uint64_t cap = pow2_at_least((uint64_t)((double)want_rows / (kMaxLoad * 0.95)) + 1);
+  int rc = alloc_arrays(&d, cap);
+  if (rc == 0) rc = reset_arrays(&d, nullptr);
+  if (rc == 0 && hipStreamSynchronize(nullptr) != hipSuccess) rc = fail("mono_table_create: sync failed");
+  if (rc != 0) {
+    free_arrays(&d);
+    if (t->slot_expire_dev) (void)hipFree(t->slot_expire_dev);
+    delete t;
+    return rc;
+  }
+  *out_table = t;
+  return 0;
+}
+
+int mono_table_destroy(void* table) {
+  if (!table) return 0;
+  Table* t = (Table*)table;
+  free_arrays(&t->d);
+  if (t->slot_expire_dev) (void)hipFree(t->slot_expire_dev);
+  t->ws.release();
+  delete t;
+  return 0;
+}
+
+int mono_table_dim(void* table) { return ((Table*)table)->d.dim; }
+int mono_table_slice_size(void* table) { return ((Table*)table)->d.n_seg; }
+int mono_table_row_floats(void* table) { return ((Table*)table)->d.row_floats; }
+
+int mono_table_lookup(void* table, const int64_t* ids, int64_t n, float* out, void* stream) {
+  MONO_REQUIRE(table, "mono_table_lookup: null table");
+  if (n == 0) return 0;
+  MONO_REQUIRE(ids && out, "mono_table_lookup: null buffer");
+  Table* t = (Table*)table;
+  hipStream_t st = (hipStream_t)stream;
+  const bool aligned = ((uintptr_t)out & 15) == 0;
+  if (t->d.dim % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) launch_lookup<4>(t, ids, n, out, st);
+  else if (t->d.dim % 2 == 0 && t->d.row_floats % 2 == 0 && aligned) launch_lookup<2>(t, ids, n, out, st);
+  else launch_lookup<1>(t, ids, n, out, st);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int mono_table_assign(void* table, void* filter, const int64_t* ids, const float* values, int64_t n,
+                      int64_t req_time, void* stream) {
+  MONO_REQUIRE(table, "mono_table_assign: null table");
+  Table* t = (Table*)table;
+  t->max_update_ts = std::max(t->max_update_ts, req_time);
+  return write_path(t, filter, ids, values, nullptr, n, MODE_ASSIGN, nullptr, 0, req_time, 0,
+                    (hipStream_t)stream);
+}
+
+int mono_table_assign_add(void* table, void* filter, const int64_t* ids, const float* values,
+                          int64_t n, int64_t req_time, void* stream) {
+  MONO_REQUIRE(table, "mono_table_assign_add: null table");
+  Table* t = (Table*)table;
+  if (n > 0) t->max_update_ts = std::max(t->max_update_ts, req_time);
+  return write_path(t, filter, ids, values, nullptr, n, MODE_ASSIGN_ADD, nullptr, 0, req_time, 1,
+                    (hipStream_t)stream);
+}
+
+int mono_table_apply_gradients(void* table, void* filter, const int64_t* ids, const float* grads,
+                               int64_t n, const float* h_learning_rates, int n_learning_rates,
+                               int64_t req_time, int64_t global_step, int enable_dedup,
+                               void* stream) {
+  (void)global_step;
+  MONO_REQUIRE(table, "mono_table_apply_gradients: null table");
+  Table* t = (Table*)table;
+  MONO_REQUIRE(n_learning_rates == t->d.n_seg,
+               "mono_table_apply_gradients: %d learning rates for %d segments", n_learning_rates,
+               t->d.n_seg);
+  t->max_update_ts = std::max(t->max_update_ts, req_time);
+  return write_path(t, filter, ids, grads, nullptr, n, enable_dedup ? MODE_OPT_DEDUP : MODE_OPT_SEQ,
+                    h_learning_rates, n_learning_rates, req_time, 0, (hipStream_t)stream);
+}
+
+int mono_table_import(void* table, const int64_t* ids, const float* rows, const uint32_t* ts,
+                      int64_t n, void* stream) {
+  MONO_REQUIRE(table, "mono_table_import: null table");
+  Table* t = (Table*)table;
+  if (n == 0) return 0;
+  // max_update_ts follows the restored timestamps (bridge :344-367)
+  std::vector<uint32_t> h(n);
+  MONO_HIP(hipMemcpyAsync(h.data(), ts, n * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  MONO_HIP(hipStreamSynchronize((hipStream_t)stream));
+  for (uint32_t v : h) t->max_update_ts = std::max<int64_t>(t->max_update_ts, v);
+  return write_path(t, nullptr, ids, rows, ts, n, MODE_IMPORT, nullptr, 0, 0, 0, (hipStream_t)stream);
+}
+
+int mono_table_size(void* table, int64_t* h_size, void* stream) {
+  MONO_REQUIRE(table && h_size, "mono_table_size: null argument");
+  int64_t live, tombs;
+  MONO_TRY(read_counters((Table*)table, (hipStream_t)stream, &live, &tombs));
+  *h_size = live;
+  return 0;
+}
+
+int mono_table_contains(void* table, const int64_t* ids, int64_t n, uint8_t* out, void* stream) {
+  MONO_REQUIRE(table, "mono_table_contains: null table");
+  if (n == 0) return 0;
+  Table* t = (Table*)table;
+  hipLaunchKernelGGL(k_contains, dim3(grid_for(n, 32)), dim3(256), 0, (hipStream_t)stream, t->d, ids,
+                     n, out);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int mono_table_clear(void* table, void* stream) {
+  MONO_REQUIRE(table, "mono_table_clear: null table");
+  Table* t = (Table*)table;
+  MONO_TRY(reset_arrays(&t->d, (hipStream_t)stream));
+  t->used_upper = 0;
+  return 0;
+}
+
+int mono_table_evict(void* table, int64_t max_update_time, void* stream) {
+  MONO_REQUIRE(table, "mono_table_evict: null table");
+  Table* t = (Table*)table;
+  hipLaunchKernelGGL(k_evict, dim3(grid_for((int64_t)t->d.cap + 2, 256)), dim3(256), 0,
+                     (hipStream_t)stream, t->d, max_update_time);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int mono_table_max_update_ts(void* table, int64_t* h_out) {
+  MONO_REQUIRE(table && h_out, "mono_table_max_update_ts: null argument");
+  *h_out = ((Table*)table)->max_update_ts;
+  return 0;
+}
+
+int mono_table_reserve(void* table, int64_t rows, void* stream) {
+  MONO_REQUIRE(table, "mono_table_reserve: null table");
+  Table* t = (Table*)table;
+  hipStream_t st = (hipStream_t)stream;
+  int64_t live, tombs;
+  MONO_TRY(read_counters(t, st, &live, &tombs));
+  const int64_t limit = (int64_t)(kMaxLoad * 0.95 * (double)t->d.cap);
+  if (std::max(rows, live) + tombs > limit) {
+    uint64_t want = pow2_at_least((uint64_t)((double)std::max(rows, live) / (kMaxLoad * 0.95)) + 1);
+    MONO_TRY(rehash(t, std::max<uint64_t>(want, 1024), st));
+    tombs = 0;
+  }
+  t->used_upper = live + tombs;
+  return 0;
+}
+
+int mono_table_export(void* table, int64_t max_rows, int apply_expiry, int64_t* ids, float* rows,
+                      uint32_t* ts, int64_t* h_count, void* stream) {
+  MONO_REQUIRE(table && h_count, "mono_table_export: null argument");
+  Table* t = (Table*)table;
+  hipStream_t st = (hipStream_t)stream;
+  MONO_HIP(hipMemsetAsync(&t->d.counters[2], 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_export, dim3(grid_for((int64_t)t->d.cap + 2, 256)), dim3(256), 0, st, t->d,
+                     max_rows, apply_expiry, t->max_update_ts, ids, rows, ts);
+  MONO_HIP(hipGetLastError());
+  unsigned long long cnt = 0;
+  MONO_HIP(hipMemcpyAsync(&cnt, &t->d.counters[2], sizeof(cnt), hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  *h_count = std::min<int64_t>((int64_t)cnt, max_rows);
+  return 0;
+}
+
+int mono_tables_fused_lookup(void* const* tables, int K, const int64_t* ids,
+                             const int32_t* h_fused_slot_size, int N, float* out_emb,
+                             int32_t* h_emb_splits, int32_t* h_id_offsets, int32_t* h_emb_offsets,
+                             int32_t* h_emb_sizes, void* stream) {
+  MONO_REQUIRE(tables && K > 0 && N > 0 && h_fused_slot_size, "mono_tables_fused_lookup: bad argument");
+  MONO_REQUIRE(h_emb_splits && h_id_offsets && h_emb_offsets && h_emb_sizes,
+               "mono_tables_fused_lookup: null metadata output");
+  // ops/hash_table_lookup_op.cc:178-203
+  const int cnt = K * N;
+  int64_t output_dim = 0, prev = 0;
+  for (int i = 0; i < cnt; ++i) h_id_offsets[i] = h_emb_offsets[i] = h_emb_sizes[i] = 0;
+  for (int shard = 0; shard < N; ++shard) {
+    for (int k = 0; k < K; ++k) {
+      int idx = K * shard + k;
+      MONO_REQUIRE(h_fused_slot_size[idx] >= 0, "mono_tables_fused_lookup: negative slot size");
+      int64_t seg_dim = (int64_t)((Table*)tables[k])->d.dim * h_fused_slot_size[idx];
+      output_dim += seg_dim;
+      MONO_REQUIRE(output_dim < (int64_t)INT32_MAX, "mono_tables_fused_lookup: int32 offset overflow");
+      h_emb_sizes[idx] = (int32_t)seg_dim;
+      if (idx > 0) {
+        h_emb_offsets[idx] = h_emb_offsets[idx - 1] + h_emb_sizes[idx - 1];
+        h_id_offsets[idx] = h_id_offsets[idx - 1] + h_fused_slot_size[idx - 1];
+      }
+    }
+    h_emb_splits[shard] = (int32_t)(output_dim - prev);
+    prev = output_dim;
+  }
+  if (!out_emb) return 0;
+  for (int idx = 0; idx < cnt; ++idx) {
+    if (h_fused_slot_size[idx] == 0) continue;
+    MONO_TRY(mono_table_lookup(tables[idx % K], ids + h_id_offsets[idx], h_fused_slot_size[idx],
+                               out_emb + h_emb_offsets[idx], stream));
+  }
+  return 0;
+}
+
+int mono_tables_fused_apply_gradient(void* const* tables, void* const* filters, int K,
+                                     const int64_t* ids, const int32_t* h_fused_slot_size,
+                                     const float* grads, const int32_t* h_id_offsets,
+                                     const int32_t* h_grad_offsets, const float* h_learning_rates,
+                                     const int32_t* h_lr_lengths, int64_t req_time,
+                                     int64_t global_step, int N, int enable_grad_accumulation,
+                                     void* stream) {
+  MONO_REQUIRE(tables && K > 0 && N > 0, "mono_tables_fused_apply_gradient: bad argument");
+  // ops/hash_table_update_op.cc:209-251; shard-major order is the canonical one
+  std::vector<int> lr_off(K, 0);
+  for (int k = 1; k < K; ++k) lr_off[k] = lr_off[k - 1] + h_lr_lengths[k - 1];
+  for (int shard = 0; shard < N; ++shard)
+    for (int k = 0; k < K; ++k) {
+      int idx = shard * K + k;
+      Table* tk = (Table*)tables[k];
+      tk->max_update_ts = std::max(tk->max_update_ts, req_time);  // bridge :233-234
+      if (h_fused_slot_size[idx] == 0) continue;
+      MONO_TRY(mono_table_apply_gradients(tables[k], filters ? filters[k] : nullptr,
+                                          ids + h_id_offsets[idx], grads + h_grad_offsets[idx],
+                                          h_fused_slot_size[idx], h_learning_rates + lr_off[k],
+                                          h_lr_lengths[k], req_time, global_step,
+                                          enable_grad_accumulation, stream));
+    }
+  return 0;
+}
+
+}  // extern "C"

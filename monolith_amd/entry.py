@@ -1,0 +1,167 @@
+"""Config builders mirroring monolith/native_training/entry.py:54-588 as plain dataclasses
+(no protobuf): optimizers (Sgd / Adagrad / Ftrl), initializers (Zeros / Constants /
+RandomUniform), CombineAsSegment, CuckooHashTableConfig, HashTableConfigInstance, and the
+table / slot-expire / slot-threshold messages of embedding_hash_table.proto:19-106.
+Defaults are the proto defaults (optimizer.proto:19-72, initializer_config.proto:19-46)."""
+import copy
+import dataclasses
+from typing import Any, Callable, Dict, List, Optional, Union
+
+OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
+INIT_ZEROS, INIT_ONES, INIT_CONSTANT, INIT_UNIFORM = 0, 1, 2, 3
+
+
+class Optimizer:
+  kind = None
+
+
+@dataclasses.dataclass
+class SgdOptimizer(Optimizer):  # entry.py:54-74
+  learning_rate: Optional[Any] = None
+  kind = OPT_SGD
+
+
+@dataclasses.dataclass
+class AdagradOptimizer(Optimizer):  # entry.py:77-112
+  learning_rate: Optional[Any] = None
+  initial_accumulator_value: Optional[float] = None
+  hessian_compression_times: int = 1
+  warmup_steps: int = 0
+  weight_decay_factor: float = 0.0
+  kind = OPT_ADAGRAD
+
+
+@dataclasses.dataclass
+class FtrlOptimizer(Optimizer):  # entry.py:342-369
+  learning_rate: Optional[Any] = None
+  initial_accumulator_value: Optional[float] = None
+  beta: Optional[float] = None
+  warmup_steps: int = 0
+  l1_regularization: Optional[float] = None
+  l2_regularization: Optional[float] = None
+  kind = OPT_FTRL
+
+
+class Initializer:
+  kind = None
+
+
+@dataclasses.dataclass
+class ZerosInitializer(Initializer):  # entry.py:381-388
+  kind = INIT_ZEROS
+
+
+@dataclasses.dataclass
+class OnesInitializer(Initializer):
+  kind = INIT_ONES
+
+
+@dataclasses.dataclass
+class ConstantsInitializer(Initializer):  # entry.py:391-400
+  constant: float = 0.0
+  kind = INIT_CONSTANT
+
+
+@dataclasses.dataclass
+class RandomUniformInitializer(Initializer):  # entry.py:403-418
+  minval: Optional[float] = None
+  maxval: Optional[float] = None
+  kind = INIT_UNIFORM
+
+
+@dataclasses.dataclass
+class Fp32Compressor:  # entry.py:482-488 (training entries ignore the compressor)
+  pass
+
+
+@dataclasses.dataclass
+class Segment:  # EntryConfig.Segment, embedding_hash_table.proto:20-28
+  dim_size: int
+  init_config: Initializer
+  opt_config: Optimizer
+  comp_config: Any = None
+
+
+def CombineAsSegment(dim_size: int, initializer: Initializer, optimizer: Optimizer,
+                     compressor: Any = None) -> Segment:  # entry.py:491-513
+  return Segment(dim_size, initializer, optimizer, compressor)
+
+
+@dataclasses.dataclass
+class SlotExpireTimeConfig:  # embedding_hash_table.proto:52-62
+  slot_expire_times: Dict[int, int] = dataclasses.field(default_factory=dict)
+  default_expire_time: int = 36500
+
+
+@dataclasses.dataclass
+class SlotOccurrenceThresholdConfig:  # embedding_hash_table.proto:89-99
+  slot_occurrence_thresholds: Dict[int, int] = dataclasses.field(default_factory=dict)
+  default_occurrence_threshold: int = 0
+
+
+@dataclasses.dataclass
+class EmbeddingHashTableConfig:  # embedding_hash_table.proto:67-87
+  segments: List[Segment] = dataclasses.field(default_factory=list)
+  initial_capacity: int = 1
+  slot_expire_time_config: SlotExpireTimeConfig = dataclasses.field(
+      default_factory=SlotExpireTimeConfig)
+  enable_feature_eviction: bool = False
+  feature_evict_every_n_hours: int = 240
+  seed: int = 0  # build-defined: seed of the counter-based random_uniform initializer
+
+  @property
+  def dim_size(self):  # hash_table_utils.py:45-50 (infer_dim_size)
+    return sum(s.dim_size for s in self.segments)
+
+  def key(self):
+    return repr(self)
+
+
+class CuckooHashTableConfig:  # entry.py:525-537
+
+  def __init__(self, initial_capacity=1, feature_evict_every_n_hours=0):
+    self._initial_capacity = initial_capacity
+    self._feature_evict_every_n_hours = feature_evict_every_n_hours
+
+  def mutate_table(self, table_config: EmbeddingHashTableConfig):
+    table_config.initial_capacity = self._initial_capacity
+    if self._feature_evict_every_n_hours > 0:
+      table_config.enable_feature_eviction = True
+      table_config.feature_evict_every_n_hours = self._feature_evict_every_n_hours
+
+
+class HashTableConfigInstance:  # entry.py:539-588
+  """The config instance for generating HashTable."""
+
+  def __init__(self, table_config: EmbeddingHashTableConfig,
+               learning_rate_fns: List[Union[float, Callable[[], float]]],
+               extra_restore_names=None):
+    self._table_config = table_config
+    self.extra_restore_names = copy.copy(extra_restore_names) or []
+    self._learning_rate_fns = learning_rate_fns
+    self._learning_rate_tensor = None
+
+  def __str__(self):  # used to check whether two slots share the same config
+    return "TableConfigPB: %s, LearningRateFns: [%s]" % (self._table_config.key(), ", ".join(
+        [str(fn) for fn in self._learning_rate_fns]))
+
+  @property
+  def table_config(self):
+    return self._table_config
+
+  @property
+  def learning_rate_fns(self):
+    return self._learning_rate_fns
+
+  @property
+  def learning_rate_tensor(self):
+    return self._learning_rate_tensor
+
+  def set_learning_rate_tensor(self, learning_rate_tensor):
+    self._learning_rate_tensor = learning_rate_tensor
+
+  def call_learning_rate_fns(self) -> List[float]:
+    """Evaluates the learning-rate functions (entry.py:571-588); one float per segment."""
+    if not self._learning_rate_fns:
+      raise Exception("Learning_rate_fns must be not empty.")
+    return [float(fn() if callable(fn) else fn) for fn in self._learning_rate_fns]

@@ -1,0 +1,394 @@
+"""Mirror of monolith/native_training/hash_table_ops.py:50-537 over the C ABI.
+
+Same class / method names, argument order and "a write returns a new table object" chaining
+as the reference; tensors are torch CUDA tensors (int64 ids, float32 values) used purely as
+device buffers. TF graph / proto / saver-listener plumbing is not reproduced.
+"""
+import abc
+import copy
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from monolith_amd import _lib
+from monolith_amd import entry
+from monolith_amd import hash_filter_ops
+
+_DEVICE = "cuda"
+
+
+def _dev():
+  return torch.device(_DEVICE, torch.cuda.current_device())
+
+
+def _ids(x) -> torch.Tensor:
+  """`ids = tf.convert_to_tensor(ids, tf.int64)` (hash_table_ops.py:254)."""
+  if not isinstance(x, torch.Tensor):
+    x = torch.as_tensor(x, dtype=torch.int64)
+  return x.to(device=_dev(), dtype=torch.int64).reshape(-1).contiguous()
+
+
+def _f32(x) -> torch.Tensor:
+  if not isinstance(x, torch.Tensor):
+    x = torch.as_tensor(x, dtype=torch.float32)
+  return x.to(device=_dev(), dtype=torch.float32).contiguous()
+
+
+def _scalar(x, default=0) -> int:
+  if x is None:
+    return default
+  if isinstance(x, torch.Tensor):
+    return int(x.item())
+  return int(x)
+
+
+class BaseHashTable(abc.ABC):
+  """hash_table_ops.py:50-128. For the write operation, it will return a new HashTable."""
+
+  @abc.abstractmethod
+  def assign(self, ids, values, req_time=None) -> "BaseHashTable":
+    pass
+
+  @abc.abstractmethod
+  def assign_add(self, ids, values, req_time=None) -> "BaseHashTable":
+    pass
+
+  @abc.abstractmethod
+  def lookup(self, ids, use_multi_threads=False, enable_dedup=False) -> torch.Tensor:
+    pass
+
+  @property
+  @abc.abstractmethod
+  def dim_size(self):
+    pass
+
+  @abc.abstractmethod
+  def apply_gradients(self, ids, grads, global_step, use_multi_threads=False, enable_dedup=False,
+                      req_time=None) -> "BaseHashTable":
+    pass
+
+  @abc.abstractmethod
+  def as_op(self):
+    pass
+
+
+class _TableResource:
+  """The ref-counted resource of ops/hash_table_op.cc:38-131: owns the mono_table handle and
+  holds a reference on its filter (hash_table_op.cc:61-63)."""
+
+  def __init__(self, table_config: entry.EmbeddingHashTableConfig,
+               hash_filter: hash_filter_ops.HashFilter):
+    segs = []
+    for s in table_config.segments:
+      o, i = s.opt_config, s.init_config
+      if not isinstance(o, (entry.SgdOptimizer, entry.AdagradOptimizer, entry.FtrlOptimizer)):
+        raise ValueError("optimizer %r is out of scope of the MI355X hot path" % (o,))
+      init_acc = getattr(o, "initial_accumulator_value", None)
+      seg = _lib.SegCfg(
+          s.dim_size, o.kind, 0.1 if init_acc is None else init_acc,
+          getattr(o, "weight_decay_factor", 0.0) or 0.0,
+          getattr(o, "l1_regularization", None) or 0.0,
+          getattr(o, "l2_regularization", None) or 0.0,
+          getattr(o, "beta", None) or 0.0, i.kind, 0.0, 0.0)
+      if isinstance(i, entry.ConstantsInitializer):
+        seg.init_a = i.constant
+      elif isinstance(i, entry.RandomUniformInitializer):
+        seg.init_a = -0.05 if i.minval is None else i.minval
+        seg.init_b = 0.05 if i.maxval is None else i.maxval
+      segs.append(seg)
+    arr = (_lib.SegCfg * len(segs))(*segs)
+    se = table_config.slot_expire_time_config.slot_expire_times
+    n = len(se)
+    sl = (C.c_int32 * max(n, 1))(*list(se.keys()))
+    dd = (C.c_int32 * max(n, 1))(*list(se.values()))
+    cfg = _lib.TableCfg(len(segs), table_config.slot_expire_time_config.default_expire_time, arr,
+                        table_config.initial_capacity, n, 0, sl, dd, table_config.seed)
+    self.h = C.c_void_p()
+    self.filter = hash_filter
+    _lib.check(_lib.lib.mono_table_create(C.byref(cfg), C.byref(self.h)))
+    self.dim = _lib.lib.mono_table_dim(self.h)
+    self.row_floats = _lib.lib.mono_table_row_floats(self.h)
+    self.slice_size = _lib.lib.mono_table_slice_size(self.h)
+
+  def __del__(self):
+    h = getattr(self, "h", None)
+    if h:
+      _lib.lib.mono_table_destroy(h)
+      self.h = None
+
+
+_NAME_SET = set()  # HashTableMetadata.name_set (hash_table_ops.py:134-137, :218-223)
+
+
+def reset_name_scope():
+  """A fresh tf.Graph in the reference; clears the shared_name registry."""
+  _NAME_SET.clear()
+
+
+class HashTable(BaseHashTable):
+  """It maps a int64 to a float32 embedding (hash_table_ops.py:149-361)."""
+
+  def __init__(self, table: _TableResource = None, shared_name: str = None, dim_size: int = None,
+               slot_expire_time_config=None, learning_rate_tensor: Sequence[float] = None,
+               saver_parallel: int = -1, extra_restore_names=None):
+    self._table = table
+    self._dim_size = dim_size
+    self._init_table_name = shared_name
+    self._check_and_insert_name(shared_name)
+    self._slot_expire_time_config = slot_expire_time_config
+    self._learning_rate_tensor = learning_rate_tensor
+    self._saver_parallel = saver_parallel
+    self._extra_restore_names = extra_restore_names or []
+    self.export_share_embedding = None
+
+  @classmethod
+  def _check_and_insert_name(cls, name):
+    if name in _NAME_SET:
+      raise ValueError("shared_name {} has already been used.".format(name))
+    _NAME_SET.add(name)
+
+  @property
+  def table(self):
+    return self._table
+
+  @property
+  def name(self):
+    return self._init_table_name
+
+  @property
+  def extra_restore_names(self):
+    return self._extra_restore_names
+
+  @property
+  def dim_size(self):
+    return self._dim_size
+
+  @property
+  def learning_rate_tensor(self):
+    lr = self._learning_rate_tensor
+    return [float(x() if callable(x) else x) for x in lr]
+
+  def _h(self):
+    return self._table.h
+
+  def _filter_h(self):
+    f = self._table.filter
+    return f.handle if f is not None else None
+
+  # ---- BaseHashTable
+  def assign(self, ids, values, req_time=None) -> "HashTable":
+    ids, values = _ids(ids), _f32(values)
+    self._check_values(ids, values)
+    _lib.check(_lib.lib.mono_table_assign(self._h(), self._filter_h(), _lib.vp(ids),
+                                          _lib.vp(values), C.c_int64(ids.numel()),
+                                          C.c_int64(_scalar(req_time)), _lib.stream_ptr()))
+    return self._copy_with_new_table(self._table)
+
+  def assign_add(self, ids, values, req_time=None) -> "HashTable":
+    ids, values = _ids(ids), _f32(values)
+    self._check_values(ids, values)
+    _lib.check(_lib.lib.mono_table_assign_add(self._h(), self._filter_h(), _lib.vp(ids),
+                                              _lib.vp(values), C.c_int64(ids.numel()),
+                                              C.c_int64(_scalar(req_time)), _lib.stream_ptr()))
+    return self._copy_with_new_table(self._table)
+
+  def lookup(self, ids, use_multi_threads=False, enable_dedup=False) -> torch.Tensor:
+    ids = _ids(ids)
+    out = torch.empty((ids.numel(), self._dim_size), dtype=torch.float32, device=ids.device)
+    _lib.check(_lib.lib.mono_table_lookup(self._h(), _lib.vp(ids), C.c_int64(ids.numel()),
+                                          _lib.vp(out), _lib.stream_ptr()))
+    return out
+
+  def apply_gradients(self, ids, grads, global_step, use_multi_threads=False, enable_dedup=False,
+                      req_time=None) -> "HashTable":
+    ids, grads = _ids(ids), _f32(grads)
+    self._check_values(ids, grads)
+    lrs = self.learning_rate_tensor
+    arr = (C.c_float * len(lrs))(*lrs)
+    _lib.check(_lib.lib.mono_table_apply_gradients(
+        self._h(), self._filter_h(), _lib.vp(ids), _lib.vp(grads), C.c_int64(ids.numel()), arr,
+        C.c_int(len(lrs)), C.c_int64(_scalar(req_time)), C.c_int64(_scalar(global_step)),
+        C.c_int(int(bool(enable_dedup))), _lib.stream_ptr()))
+    return self._copy_with_new_table(self._table)
+
+  def as_op(self):
+    return self._table
+
+  def table_update(self, update_op) -> "HashTable":
+    return self._copy_with_new_table(self._table)
+
+  def _copy_with_new_table(self, new_table):
+    copied = copy.copy(self)
+    copied.__dict__["_table"] = new_table
+    return copied
+
+  def _check_values(self, ids, values):
+    # OP_REQUIRES / ValidateDim (embedding_hash_table_tf_bridge.cc:38-44)
+    if values.numel() != ids.numel() * self._dim_size:
+      raise _lib.MonolithHipError("The dim doesn't match expectation. %d vs %d" %
+                                  (values.numel(), ids.numel() * self._dim_size))
+
+  # ---- extras of the reference class
+  def size(self) -> int:
+    out = C.c_int64()
+    _lib.check(_lib.lib.mono_table_size(self._h(), C.byref(out), _lib.stream_ptr()))
+    return int(out.value)
+
+  def contains(self, ids) -> torch.Tensor:
+    ids = _ids(ids)
+    out = torch.empty(ids.numel(), dtype=torch.uint8, device=ids.device)
+    _lib.check(_lib.lib.mono_table_contains(self._h(), _lib.vp(ids), C.c_int64(ids.numel()),
+                                            _lib.vp(out), _lib.stream_ptr()))
+    return out.bool()
+
+  def clear(self) -> "HashTable":
+    _lib.check(_lib.lib.mono_table_clear(self._h(), _lib.stream_ptr()))
+    return self._copy_with_new_table(self._table)
+
+  def evict(self, max_update_time: int) -> "HashTable":
+    """CuckooEmbeddingHashTable::Evict, driven by the caller instead of the bridge's
+    background thread (embedding_hash_table_tf_bridge.cc:69-100)."""
+    _lib.check(_lib.lib.mono_table_evict(self._h(), C.c_int64(int(max_update_time)),
+                                         _lib.stream_ptr()))
+    return self._copy_with_new_table(self._table)
+
+  def max_update_ts(self) -> int:
+    out = C.c_int64()
+    _lib.check(_lib.lib.mono_table_max_update_ts(self._h(), C.byref(out)))
+    return int(out.value)
+
+  def reserve(self, rows: int) -> "HashTable":
+    _lib.check(_lib.lib.mono_table_reserve(self._h(), C.c_int64(int(rows)), _lib.stream_ptr()))
+    return self
+
+  def save_as_tensor(self, apply_expiry=False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Dump (ids, rows[dim + optimizer state], last_update_ts). The reference emits serialized
+    EntryDump protos (hash_table_ops.py:335-361); the payload is the same three fields."""
+    n = self.size()
+    dev = _dev()
+    ids = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    rows = torch.empty((max(n, 1), self._table.row_floats), dtype=torch.float32, device=dev)
+    ts = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    cnt = C.c_int64()
+    _lib.check(_lib.lib.mono_table_export(self._h(), C.c_int64(n), C.c_int(int(apply_expiry)),
+                                          _lib.vp(ids), _lib.vp(rows), _lib.vp(ts), C.byref(cnt),
+                                          _lib.stream_ptr()))
+    k = int(cnt.value)
+    return ids[:k], rows[:k], ts[:k]
+
+  def restore_from_tensor(self, ids, rows, ts) -> "HashTable":
+    """Clear + upsert of full entries (ops/hash_table_restore_op.cc:82-131)."""
+    self.clear()
+    ids = _ids(ids)
+    rows = _f32(rows)
+    ts = ts.to(device=_dev(), dtype=torch.int32).contiguous()
+    _lib.check(_lib.lib.mono_table_import(self._h(), _lib.vp(ids), _lib.vp(rows), _lib.vp(ts),
+                                          C.c_int64(ids.numel()), _lib.stream_ptr()))
+    return self._copy_with_new_table(self._table)
+
+
+def _handles(tables):
+  res = [t.table if isinstance(t, HashTable) else t for t in tables]
+  return res, (C.c_void_p * len(res))(*[r.h.value for r in res])
+
+
+def fused_lookup(tables: List, ids, fused_slot_size, num_of_shards: int):
+  """A fused operation for lookup (hash_table_ops.py:364-399).
+
+  Returns (embeddings, recv_splits, id_offsets, emb_offsets, embedding_sizes): the flat
+  embeddings on the device, the four int32 metadata vectors as CPU tensors."""
+  res, hs = _handles(tables)
+  K, N = len(res), int(num_of_shards)
+  ids = _ids(ids)
+  fss = torch.as_tensor(fused_slot_size, dtype=torch.int32).cpu().contiguous()
+  if fss.numel() != K * N:
+    raise _lib.MonolithHipError("len(fused_slot_size) / num_of_shards != len(table_handles)")
+  if int(fss.sum()) != ids.numel():
+    raise _lib.MonolithHipError("sum(fused_slot_size) != len(ids)")
+  splits = torch.zeros(N, dtype=torch.int32)
+  id_off = torch.zeros(K * N, dtype=torch.int32)
+  emb_off = torch.zeros(K * N, dtype=torch.int32)
+  emb_sizes = torch.zeros(K * N, dtype=torch.int32)
+  args = (hs, C.c_int(K), _lib.vp(ids), C.c_void_p(fss.data_ptr()), C.c_int(N))
+  meta = (C.c_void_p(splits.data_ptr()), C.c_void_p(id_off.data_ptr()),
+          C.c_void_p(emb_off.data_ptr()), C.c_void_p(emb_sizes.data_ptr()))
+  _lib.check(_lib.lib.mono_tables_fused_lookup(*args, None, *meta, _lib.stream_ptr()))
+  emb = torch.empty(int(splits.sum()), dtype=torch.float32, device=ids.device)
+  _lib.check(_lib.lib.mono_tables_fused_lookup(*args, _lib.vp(emb), *meta, _lib.stream_ptr()))
+  return emb, splits, id_off, emb_off, emb_sizes
+
+
+def fused_apply_gradient(tables: List, ids, fused_slot_size, id_grads, id_offsets, grad_offsets,
+                         learning_rate_tensors, learning_rate_lengths, req_time, global_step,
+                         num_of_shards: int, enable_grad_accumulation: bool = False):
+  """A fused operation for applying gradients (hash_table_ops.py:402-455)."""
+  res, hs = _handles(tables)
+  K, N = len(res), int(num_of_shards)
+  ids = _ids(ids)
+  grads = _f32(id_grads).reshape(-1)
+  fss = torch.as_tensor(fused_slot_size, dtype=torch.int32).cpu().contiguous()
+  io = torch.as_tensor(id_offsets, dtype=torch.int32).cpu().contiguous()
+  go = torch.as_tensor(grad_offsets, dtype=torch.int32).cpu().contiguous()
+  lrs = torch.as_tensor(learning_rate_tensors, dtype=torch.float32).cpu().contiguous()
+  lrl = torch.as_tensor(learning_rate_lengths, dtype=torch.int32).cpu().contiguous()
+  if fss.numel() != K * N:
+    raise _lib.MonolithHipError("len(fused_slot_size) / num_of_shards != len(table_handles)")
+  fs = (C.c_void_p * K)(*[(r.filter.handle.value if r.filter is not None else None) for r in res])
+  _lib.check(_lib.lib.mono_tables_fused_apply_gradient(
+      hs, fs, C.c_int(K), _lib.vp(ids), C.c_void_p(fss.data_ptr()), _lib.vp(grads),
+      C.c_void_p(io.data_ptr()), C.c_void_p(go.data_ptr()), C.c_void_p(lrs.data_ptr()),
+      C.c_void_p(lrl.data_ptr()), C.c_int64(_scalar(req_time)), C.c_int64(_scalar(global_step)),
+      C.c_int(N), C.c_int(int(bool(enable_grad_accumulation))), _lib.stream_ptr()))
+  return tables
+
+
+def hash_table_from_config(config: entry.HashTableConfigInstance,
+                           hash_filter: Optional[hash_filter_ops.HashFilter] = None,
+                           name_suffix="", sync_client=None, saver_parallel: int = -1) -> HashTable:
+  """hash_table_ops.py:458-492."""
+  table_config = config.table_config
+  dim_size = table_config.dim_size
+  hash_table_name = "MonolithHashTable_" + name_suffix
+  if hash_filter is None:
+    hash_filter = hash_filter_ops.create_dummy_hash_filter(name_suffix=name_suffix)
+  if len(config.learning_rate_fns) != len(table_config.segments):
+    raise ValueError("Size of learning_rate_fns and size of segments must be equal.")
+  return HashTable(_TableResource(table_config, hash_filter), shared_name=hash_table_name,
+                   dim_size=dim_size,
+                   slot_expire_time_config=table_config.slot_expire_time_config,
+                   learning_rate_tensor=list(config.learning_rate_fns),
+                   saver_parallel=saver_parallel, extra_restore_names=config.extra_restore_names)
+
+
+_TEST_COUNTER = [0]
+
+
+def test_hash_table(dim_size, enable_hash_filter=False, name_suffix=None, learning_rate=1.0,
+                    occurrence_threshold=0, use_adagrad=False, expire_time=36500,
+                    sync_client=None, extra_restore_names=None,
+                    filter_capacity=hash_filter_ops.HASH_FILTER_CAPACITY) -> HashTable:
+  """Returns a hash table which essentially is a |dim_size| float table with sgd optimizer
+  (hash_table_ops.py:495-537)."""
+  opt = entry.AdagradOptimizer() if use_adagrad else entry.SgdOptimizer()
+  table_config = entry.EmbeddingHashTableConfig(
+      segments=[entry.CombineAsSegment(dim_size, entry.ZerosInitializer(), opt,
+                                       entry.Fp32Compressor())])
+  table_config.slot_expire_time_config.default_expire_time = expire_time
+  thr = entry.SlotOccurrenceThresholdConfig(default_occurrence_threshold=occurrence_threshold)
+  config = entry.HashTableConfigInstance(table_config, [learning_rate],
+                                         extra_restore_names=extra_restore_names)
+  hash_filters = hash_filter_ops.create_hash_filters(0, enable_hash_filter, thr,
+                                                     filter_capacity=filter_capacity)
+  if not name_suffix:
+    _TEST_COUNTER[0] += 1
+    name_suffix = "test_%d" % _TEST_COUNTER[0]
+  return hash_table_from_config(config=config, hash_filter=hash_filters[0],
+                                name_suffix=name_suffix, sync_client=sync_client)
+
+
+def vocab_hash_table(vocab_size: int, dim_size: int, enable_hash_filter=False,
+                     learning_rate=1.0) -> HashTable:
+  """hash_table_ops.py:540-552."""
+  return test_hash_table(dim_size, enable_hash_filter=enable_hash_filter,
+                         learning_rate=learning_rate)

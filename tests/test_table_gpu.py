@@ -1,0 +1,167 @@
+"""GPU parity: the HIP table through the C ABI vs the CPU oracle and the reference's vectors."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu
+from tests import hip_backend, oracle_backend
+from tests.scenario import load_scenarios, run_scenario
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("sc", load_scenarios(), ids=lambda s: s["name"])
+def test_reference_scenarios(sc):
+  """The reference's own unit-test vectors, replayed through libmonolith_hip.so."""
+  run_scenario(hip_backend, sc)
+
+
+def _pair(cfg, filt_cfg=None):
+  of = oracle_backend.make_filter(filt_cfg) if filt_cfg else None
+  hf = hip_backend.make_filter(filt_cfg) if filt_cfg else None
+  return oracle_backend.make_table(cfg), hip_backend.make_table(cfg, hf), of, hf
+
+
+def _assert_same_state(o, h, exact=True):
+  oi, orows, ots = o.export()
+  hi, hrows, hts = h.export()
+  assert np.array_equal(oi, hi), "key sets differ"
+  assert np.array_equal(ots, hts), "timestamps differ"
+  if exact:
+    assert np.array_equal(orows.view(np.uint32), hrows.view(np.uint32)), \
+        "rows differ (max abs %g)" % np.abs(orows - hrows).max()
+  else:
+    np.testing.assert_allclose(hrows, orows, rtol=1e-6, atol=1e-7)
+  assert o.size() == h.size()
+
+
+CFGS = {
+    "sgd1": {"segments": [{"dim": 1, "opt": "sgd"}]},
+    "sgd3": {"segments": [{"dim": 3, "opt": "sgd", "init": "constant", "init_a": 0.25}]},
+    "adagrad16": {"segments": [{"dim": 16, "opt": "adagrad", "init": "uniform", "init_a": -0.05,
+                                "init_b": 0.05}], "seed": 7},
+    "adagrad16wd": {"segments": [{"dim": 16, "opt": "adagrad", "weight_decay": 0.1,
+                                  "init": "ones"}]},
+    "ftrl16": {"segments": [{"dim": 16, "opt": "ftrl", "beta": 1.0, "l1": 0.01, "l2": 0.1}]},
+    "ftrl6": {"segments": [{"dim": 6, "opt": "ftrl"}]},
+    "adagrad64": {"segments": [{"dim": 64, "opt": "adagrad"}]},
+    "demo_ftrl1_sgd16": {"segments": [{"dim": 1, "opt": "ftrl", "init_acc": 1e-6, "beta": 1.0},
+                                      {"dim": 16, "opt": "sgd", "init": "uniform",
+                                       "init_a": -0.1, "init_b": 0.1}]},
+    "multi3": {"segments": [{"dim": 2, "opt": "adagrad"}, {"dim": 5, "opt": "ftrl", "l1": 0.001},
+                            {"dim": 1, "opt": "sgd", "init": "ones"}]},
+}
+
+
+@pytest.mark.parametrize("name", list(CFGS))
+@pytest.mark.parametrize("dedup", [False, True])
+def test_random_stream_bit_exact(name, dedup):
+  """Seeded id streams with heavy duplication, growth through several rehashes, all write ops:
+  table state (keys, rows incl. optimizer state, timestamps) bit-identical to the oracle."""
+  cfg = CFGS[name]
+  o, h, _, _ = _pair(cfg)
+  rng = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode()) % 1000 + int(dedup)))
+  D, nseg = o.dim, len(cfg["segments"])
+  for step in range(6):
+    n = int(rng.integers(1, 4000))
+    vocab = int(rng.choice([8, 300, 20000]))
+    ids = (rng.integers(0, vocab, n) * 2654435761 - 5).astype(np.int64)
+    if step == 2:
+      ids[:4] = [-1, -2, -1, 0]  # the two sentinel-valued keys
+    g = rng.normal(0, 0.1, (n, D)).astype(np.float32)
+    lrs = rng.uniform(0.001, 0.1, nseg).astype(np.float32)
+    for t in (o, h):
+      t.apply_gradients(ids, g, lrs, req_time=1000 + step, enable_dedup=dedup)
+    q = np.concatenate([ids[:50], rng.integers(-5, 5, 10)])
+    assert np.array_equal(o.lookup(q).view(np.uint32), h.lookup(q).view(np.uint32))
+    if step % 2 == 1:
+      v = rng.normal(0, 1, (n, D)).astype(np.float32)
+      for t in (o, h):
+        t.assign_add(ids, v, req_time=2000 + step)
+      m = max(1, n // 3)
+      for t in (o, h):
+        t.assign(ids[:m], v[:m], req_time=3000 + step)
+    assert np.array_equal(o.contains(q), h.contains(q))
+  _assert_same_state(o, h)
+  assert o.max_update_ts() == h.max_update_ts()
+
+
+def test_empty_and_ragged_inputs():
+  o, h, _, _ = _pair(CFGS["adagrad16"])
+  e = np.zeros(0, np.int64)
+  for t in (o, h):
+    t.apply_gradients(e, np.zeros((0, 16), np.float32), [0.1])
+    t.assign(e, np.zeros((0, 16), np.float32))
+    t.assign_add(e, np.zeros((0, 16), np.float32))
+  assert h.lookup(e).shape == (0, 16) and h.size() == 0
+  assert np.array_equal(h.lookup([1, 2, 3]), np.zeros((3, 16), np.float32))
+  with pytest.raises(Exception):
+    h.t.assign([1, 2], np.zeros((2, 5), np.float32))
+
+
+def test_evict_and_save_time_expiry():
+  """cuckoo_embedding_hash_table.cc:220-233 + hash_table_save_op.cc:142-150 on a seeded stream
+  with per-slot expire days."""
+  cfg = {"segments": [{"dim": 4, "opt": "adagrad"}], "default_expire_days": 10,
+         "slot_expire": {"1": 1, "2": 0, "3": 100}}
+  o, h, _, _ = _pair(cfg)
+  rng = np.random.Generator(np.random.PCG64(5))
+  for step in range(5):
+    slots = rng.integers(0, 5, 3000)
+    ids = ((slots.astype(np.int64) << 48) | rng.integers(0, 2000, 3000)).astype(np.int64)
+    g = rng.normal(0, 1, (3000, 4)).astype(np.float32)
+    for t in (o, h):
+      t.apply_gradients(ids, g, [0.05], req_time=86400 * step * 3, enable_dedup=True)
+  oi, _, _ = o.export(apply_expiry=True)
+  hi, _, _ = h.export(apply_expiry=True)
+  assert np.array_equal(oi, hi) and len(oi) < o.size()
+  for now in (86400 * 4, 86400 * 13, 86400 * 40):
+    o.evict(now); h.evict(now)
+    _assert_same_state(o, h)
+  # evicted keys can be re-inserted (tombstones are skipped, not resurrected)
+  ids = np.arange(100, dtype=np.int64) | (2 << 48)
+  for t in (o, h):
+    t.assign_add(ids, np.ones((100, 4), np.float32), req_time=86400 * 41)
+  _assert_same_state(o, h)
+
+
+def test_save_restore_roundtrip():
+  """hash_table_restore_op.cc:82-131: clear + upsert of (id, row incl. optimizer state, ts)."""
+  o, h, _, _ = _pair(CFGS["ftrl16"])
+  rng = np.random.Generator(np.random.PCG64(9))
+  ids = rng.integers(-1000, 1000, 5000).astype(np.int64)
+  g = rng.normal(0, 1, (5000, 16)).astype(np.float32)
+  for t in (o, h):
+    t.apply_gradients(ids, g, [0.01], req_time=77, enable_dedup=False)
+  dids, drows, dts = h.t.save_as_tensor()
+  h2 = hip_backend.make_table(CFGS["ftrl16"])
+  h2.t.restore_from_tensor(dids, drows, dts)
+  _assert_same_state(o, h2)
+  assert h2.max_update_ts() == 77
+
+
+def test_filter_gate_closed_forms():
+  """SURVEY.md §8a closed forms of the hash-filter gate (bridge :167-176, :195-198, :274-291)
+  for Optimize (dedup / no dedup), Assign and AssignAdd, on collision-free id streams."""
+  fcfg = {"kind": "sliding", "capacity": 200000, "split_num": 7, "default_threshold": 3,
+          "slot_thresholds": {"2": 0, "3": 20, "4": 1}}
+  for dedup in (False, True):
+    o, h, of, hf = _pair(CFGS["sgd3"], fcfg)
+    rng = np.random.Generator(np.random.PCG64(11 + dedup))
+    for step in range(8):
+      slots = rng.integers(0, 6, 600)
+      ids = ((slots.astype(np.int64) << 48) | rng.integers(0, 60, 600)).astype(np.int64)
+      g = rng.normal(0, 1, (600, 3)).astype(np.float32)
+      o.apply_gradients(ids, g, [0.1], req_time=step, enable_dedup=dedup, filt=of)
+      h.apply_gradients(ids, g, [0.1], req_time=step, enable_dedup=dedup, filt=hf)
+      if step == 3:
+        o.assign_add(ids[:200], g[:200], req_time=step, filt=of)
+        h.assign_add(ids[:200], g[:200], req_time=step, filt=hf)
+      if step == 5:
+        o.assign(ids[:200], g[:200], req_time=step, filt=of)
+        h.assign(ids[:200], g[:200], req_time=step, filt=hf)
+      _assert_same_state(o, h)
+      probe = np.unique(ids)
+      assert np.array_equal(of.get(probe), hf.get(torch.as_tensor(probe).cuda()).cpu().numpy())
