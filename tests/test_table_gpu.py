@@ -151,8 +151,10 @@ def test_filter_gate_closed_forms():
     o, h, of, hf = _pair(CFGS["sgd3"], fcfg)
     rng = np.random.Generator(np.random.PCG64(11 + dedup))
     for step in range(8):
-      slots = rng.integers(0, 6, 600)
-      ids = ((slots.astype(np.int64) << 48) | rng.integers(0, 60, 600)).astype(np.int64)
+      slots = rng.integers(0, 6, 600).astype(np.int64)
+      k = rng.integers(0, 60, 600).astype(np.int64)
+      # distinct 12-bit signatures (bits 17..28) so that no two fids alias in the filter
+      ids = (slots << 48) | ((slots * 60 + k) << 17) | k
       g = rng.normal(0, 1, (600, 3)).astype(np.float32)
       o.apply_gradients(ids, g, [0.1], req_time=step, enable_dedup=dedup, filt=of)
       h.apply_gradients(ids, g, [0.1], req_time=step, enable_dedup=dedup, filt=hf)
