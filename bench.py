@@ -1,0 +1,219 @@
+"""bench.py — BASELINE.json config 2 on MI355X: synthetic Criteo-shaped stream, 26 single-hot
+slots, 1e8-row table, dim 16 fp32, batch 65536, Adagrad. One step = lookup of every FID
+occurrence + apply_gradients (dedup) of one gradient row per occurrence.
+
+  python bench.py [--gpus N --steps K --warmup W]     (N > 1: launched by torch.distributed.run)
+
+metric value = (lookups + updates) / s = 2 * n * N / t_step, inputs resident in HBM.
+Multi-GPU: every rank owns an independent table + stream (weak scaling, no collective in the
+data path); the FID/embedding all-to-all path is measured by `--workload sharded`.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+SLOT_VOCAB = [40000000, 20000000, 10000000, 10000000, 5000000, 5000000, 3000000, 2000000,
+              1000000, 1000000, 500000, 500000, 200000, 100000, 100000, 50000, 20000, 10000,
+              10000, 5000, 2000, 1000, 500, 100, 50, 10]
+SLOT_VOCAB[0] += 100000000 - sum(SLOT_VOCAB)  # 26 slots, exactly 1e8 FIDs
+
+
+def make_batch(gen, batch, device, skew):
+  """fid = slot << 48 | r, r ~ truncated power law over the slot's vocabulary."""
+  vocab = torch.tensor(SLOT_VOCAB, dtype=torch.float64, device=device)
+  u = torch.rand((batch, len(SLOT_VOCAB)), generator=gen, device=device, dtype=torch.float64)
+  r = (vocab * u.pow(skew)).to(torch.int64)
+  r = torch.minimum(r, (vocab - 1).to(torch.int64))
+  slots = torch.arange(len(SLOT_VOCAB), device=device, dtype=torch.int64) << 48
+  return (slots | r).reshape(-1).contiguous()
+
+
+def populate(table, device, rows_per_slot_cap=None):
+  """Pre-populates every FID of every slot (rows U(-0.05, 0.05) via the table initializer,
+  Adagrad accumulators 0.1) with zero-valued assign_add in 4M-id chunks."""
+  chunk = 1 << 22
+  zeros = torch.zeros((chunk, 16), dtype=torch.float32, device=device)
+  t0 = time.time()
+  for s, v in enumerate(SLOT_VOCAB):
+    for lo in range(0, v, chunk):
+      n = min(chunk, v - lo)
+      ids = (torch.arange(lo, lo + n, device=device, dtype=torch.int64) | (s << 48))
+      table.assign_add(ids, zeros[:n], req_time=1)
+  torch.cuda.synchronize()
+  return time.time() - t0
+
+
+def cpu_baseline(ids_batches, grad, lr):
+  """The CPU oracle (single thread, 'port') on a bounded sample of the same stream: a table
+  holding exactly the FIDs of the sampled batches, then lookup + apply_gradients(dedup)."""
+  from oracle import cpu
+  t = cpu.OracleTable([cpu.seg(16, "adagrad", "uniform", init_a=-0.05, init_b=0.05)])
+  ids_np = [b.cpu().numpy() for b in ids_batches]
+  g = grad.cpu().numpy()
+  for b in ids_np:
+    t.assign_add(b, np.zeros((len(b), 16), np.float32))
+  n = 0
+  t0 = time.time()
+  for b in ids_np:
+    t.lookup(b)
+    t.apply_gradients(b, g[:len(b)], [lr], req_time=2, enable_dedup=True)
+    n += len(b)
+  dt = time.time() - t0
+  return {"value": 2.0 * n / dt, "unit": "lookups+updates/s", "cores": 1, "kind": "port",
+          "sample": "%d batches of %d FIDs (same stream), table holding only those FIDs (%d rows)"
+                    % (len(ids_np), len(ids_np[0]), t.size())}
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=20)
+  ap.add_argument("--warmup", type=int, default=3)
+  ap.add_argument("--batch", type=int, default=65536)
+  ap.add_argument("--rows", type=float, default=1e8, help="debug: scale the table down")
+  ap.add_argument("--skew", type=float, default=3.0, help="power-law exponent (1 = uniform)")
+  ap.add_argument("--no-cpu", action="store_true")
+  args = ap.parse_args()
+
+  rank = int(os.environ.get("RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  torch.cuda.set_device(local_rank)
+  device = torch.device("cuda", local_rank)
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("nccl", device_id=device)
+
+  from monolith_amd import _lib, entry, hash_table_ops
+  global SLOT_VOCAB
+  if args.rows != 1e8:
+    scale = args.rows / 1e8
+    SLOT_VOCAB = [max(10, int(v * scale)) for v in SLOT_VOCAB]
+  total_rows = sum(SLOT_VOCAB)
+
+  lr = 0.01
+  tc = entry.EmbeddingHashTableConfig(
+      segments=[entry.CombineAsSegment(16, entry.RandomUniformInitializer(-0.05, 0.05),
+                                       entry.AdagradOptimizer(initial_accumulator_value=0.1))],
+      initial_capacity=int(total_rows * 1.02), seed=1234 + rank)
+  table = hash_table_ops.hash_table_from_config(entry.HashTableConfigInstance(tc, [lr]),
+                                                name_suffix="bench%d" % rank)
+  t_pop = populate(table, device)
+  rows_live = table.size()
+  assert rows_live == total_rows, (rows_live, total_rows)
+
+  gen = torch.Generator(device=device)
+  gen.manual_seed(20250117 + rank)
+  n_pool = 8
+  pool = [make_batch(gen, args.batch, device, args.skew) for _ in range(n_pool)]
+  n = pool[0].numel()
+  grad = (torch.randn((n, 16), generator=gen, device=device, dtype=torch.float32) * 0.1)
+  uniq = float(np.mean([torch.unique(b).numel() / n for b in pool]))
+  out = torch.empty((n, 16), dtype=torch.float32, device=device)
+  h = table.table.h
+  lrs = (C.c_float * 1)(lr)
+  stream = torch.cuda.current_stream(device)
+  sp = C.c_void_p(stream.cuda_stream)
+
+  def step(i):
+    ids = pool[i % n_pool]
+    _lib.check(_lib.lib.mono_table_lookup(h, _lib.vp(ids), C.c_int64(n), _lib.vp(out), sp))
+    _lib.check(_lib.lib.mono_table_apply_gradients(h, None, _lib.vp(ids), _lib.vp(grad),
+                                                   C.c_int64(n), lrs, C.c_int(1), C.c_int64(10 + i),
+                                                   C.c_int64(i), C.c_int(1), sp))
+
+  def barrier():
+    if world > 1:
+      torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+  for i in range(args.warmup):
+    step(i)
+  barrier()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    step(args.warmup + i)
+  barrier()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+  ms_per_step = dt / args.steps * 1e3
+
+  # ---- per-kernel timing with HIP events on the launch stream (roofline leg, untimed region)
+  _lib.check(_lib.lib.mono_table_profile(h, 1))
+  ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  lk, ph = [], []
+  ms3 = (C.c_float * 3)()
+  for i in range(10):
+    ids = pool[i % n_pool]
+    ev0.record(stream)
+    _lib.check(_lib.lib.mono_table_lookup(h, _lib.vp(ids), C.c_int64(n), _lib.vp(out), sp))
+    ev1.record(stream)
+    _lib.check(_lib.lib.mono_table_apply_gradients(h, None, _lib.vp(ids), _lib.vp(grad),
+                                                   C.c_int64(n), lrs, C.c_int(1), C.c_int64(99),
+                                                   C.c_int64(i), C.c_int(1), sp))
+    _lib.check(_lib.lib.mono_table_last_phase_ms(h, ms3))
+    torch.cuda.synchronize()
+    lk.append(ev0.elapsed_time(ev1))
+    ph.append([ms3[0], ms3[1], ms3[2]])
+  _lib.check(_lib.lib.mono_table_profile(h, 0))
+  lk_ms = float(np.mean(lk[2:]))
+  find_ms, sort_ms, apply_ms = [float(x) for x in np.mean(np.array(ph[2:]), axis=0)]
+
+  # algorithmic bytes (SURVEY.md §8d, D = 16, Adagrad): lookup 144 B / occurrence;
+  # update 72 B / occurrence + 268 B / unique FID  (u/n measured on the stream)
+  D = 16
+  lookup_bytes = n * (8 + 8 + 4 * D + 4 * D)
+  update_bytes = n * (8 + 4 * D) + uniq * n * (8 + 2 * (4 * D + 4 * D) + 4)
+  # per kernel: resolve = id + key slot read, slot + index write; apply = grad rows +
+  # row/state read+write + ts (the part of §8d's update figure this kernel moves)
+  kern = {
+      "k_lookup": (lk_ms, lookup_bytes),
+      "k_find_or_claim": (find_ms, n * (8 + 8)),
+      "radix_sort(slot,idx)": (sort_ms, 0),
+      "k_apply": (apply_ms, n * 4 * D + uniq * n * (2 * (4 * D + 4 * D) + 4)),
+  }
+  dom = max(("k_lookup", "k_find_or_claim", "k_apply"), key=lambda k: kern[k][0])
+  achieved = kern[dom][1] / (kern[dom][0] * 1e-3) / 1e9
+  step_gbs = (lookup_bytes + update_bytes) / (ms_per_step * 1e-3) / 1e9
+
+  res = {
+      "metric": "FID lookups+updates/sec (node)", "value": 2.0 * n * world / (dt / args.steps),
+      "unit": "lookups+updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+      "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "config": {"workload": "criteo-shaped: 26 single-hot slots, %.3g-row table, dim 16 fp32, "
+                             "batch %d, Adagrad, lookup + apply_gradients(dedup)" %
+                             (total_rows, args.batch),
+                 "fids_per_step": n, "unique_ratio": uniq, "skew": args.skew,
+                 "parallelism": "independent table per GPU" if world > 1 else "1 GPU",
+                 "populate_s": t_pop, "table_rows": rows_live},
+      "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                   "kernel_ms": {k: v[0] for k, v in kern.items()},
+                   "step_algorithmic_GBps": step_gbs, "step_frac": step_gbs / HBM_PEAK_GBS},
+  }
+  if rank == 0 and world == 1 and not args.no_cpu:
+    res["cpu_baseline"] = cpu_baseline(pool[:2], grad, lr)
+  elif rank == 0:
+    res["cpu_baseline"] = None
+  if rank == 0:
+    print(json.dumps(res))
+  if world > 1:
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -122,6 +122,12 @@ int mono_table_export(void* table, int64_t max_rows, int apply_expiry, int64_t* 
 /* Restore path (ops/hash_table_restore_op.cc:82-131): upsert full rows (value + optimizer state + ts). */
 int mono_table_import(void* table, const int64_t* ids, const float* rows, const uint32_t* ts,
                       int64_t n, void* stream);
+/* Measurement hooks (no reference counterpart; bench.py's roofline leg): when enabled, every
+ * write-path call records HIP events on its own stream around its three phases;
+ * mono_table_last_phase_ms waits for the last call and returns
+ * h_ms[3] = {resolve slots (find/claim), group (radix sort), apply rows}. */
+int mono_table_profile(void* table, int enable);
+int mono_table_last_phase_ms(void* table, float* h_ms);
 /* Floats per stored row: dim + optimizer state. */
 int mono_table_row_floats(void* table);
 

@@ -69,6 +69,9 @@ struct Table {
   int64_t max_update_ts = 0;
   int32_t* slot_expire_dev = nullptr;
   Workspace ws;
+  // optional per-phase timing of the write path (mono_table_profile)
+  bool profile = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -268,6 +271,7 @@ __global__ void k_iota(uint32_t* idx, int64_t n) {
     idx[i] = (uint32_t)i;
 }
 
+struct LongSeg;
 struct ApplyArgs {
   const void* skeys;     // sorted uint32 slots, or sorted int64 keys when from_keys
   const uint32_t* sidx;  // occurrence index of each sorted position
@@ -280,7 +284,17 @@ struct ApplyArgs {
   float lr[kMaxSeg];
   FilterDev filt;  // from_keys only; filt.kind == 0 -> no gate
   int assign_add_semantics;  // filter gate of the per-id AssignAdd loop (bridge :186-209)
+  struct LongSeg* queue;     // segments longer than kLongSeg, drained by k_apply_long
+  uint32_t* qcount;
 };
+
+// A key with many occurrences in one batch (a Zipf head): handed to a whole workgroup.
+struct LongSeg {
+  int64_t first, end, key;
+  uint32_t slot, fresh;
+};
+constexpr int kLongSeg = 96;       // occurrences above which a segment goes to k_apply_long
+constexpr int kTileFloats = 2048;  // LDS staging tile (8 KB), double buffered
 
 template <typename K>
 __device__ inline int64_t segment_end(const K* keys, int64_t j, int64_t n, K key) {
@@ -388,6 +402,17 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
       fresh = claimed;
       if (claimed && sub == 0) atomicAdd(&t.counters[0], 1ull);
     }
+  }
+
+  if (end - first > kLongSeg &&
+      (a.mode == MODE_ASSIGN_ADD || a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP)) {
+    if (sub == 0) {
+      uint32_t q = atomicAdd(a.qcount, 1u);
+      LongSeg ls;
+      ls.first = first; ls.end = end; ls.key = key; ls.slot = slot; ls.fresh = fresh;
+      a.queue[q] = ls;
+    }
+    return;
   }
 
   float* row = t.rows + (uint64_t)slot * R;
@@ -501,6 +526,123 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
     }
   }
   if (sub == 0) t.ts[slot] = a.ts;
+}
+
+// Long segments: one 256-thread workgroup per key. All threads gather the next tile of
+// occurrence rows (coalesced 64 B+ pieces) while thread e < dim walks the current tile out of
+// LDS, so the adds / optimizer steps stay in input order (bit-exact with the sequential
+// reference) and the gather latency hides behind the dependent chain.
+template <int OPTK>
+__global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
+  __shared__ float tile[2][kTileFloats];
+  const int D = t.dim, R = t.row_floats;
+  const int tid = threadIdx.x;
+  const int rows_per_tile = kTileFloats / D;  // host guarantees D <= kTileFloats
+  const uint32_t nq = *a.qcount;
+  constexpr int kStage = kTileFloats / 256;
+  for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+    const LongSeg ls = a.queue[qi];
+    float* row = t.rows + (uint64_t)ls.slot * R;
+    for (int eb = 0; eb < D; eb += 256) {  // element blocks (one pass for dim <= 256)
+      const int e = eb + tid;
+      const bool owner = e < D;
+      int kind = OPTK, segi = 0, st0 = D + e, st1 = 2 * D + e;
+      if (OPTK == OPTK_MULTI && owner) {
+        for (int z = 0; z < t.n_seg; ++z)
+          if (e >= t.seg[z].w_off && e < t.seg[z].w_off + t.seg[z].dim) segi = z;
+        kind = t.seg[segi].opt_kind;
+        st0 = t.seg[segi].st_off + (e - t.seg[segi].w_off);
+        st1 = st0 + t.seg[segi].dim;
+      }
+      float w = 0.f, s0 = 0.f, s1 = 0.f, acc = 0.f;
+      const bool need_state = a.mode >= MODE_OPT_SEQ;
+      if (owner) {
+        if (ls.fresh) {
+          w = row_init_value(t, ls.key, e);
+          s0 = kind != MONO_OPT_SGD ? row_init_value(t, ls.key, st0) : 0.f;
+          s1 = kind == MONO_OPT_FTRL ? row_init_value(t, ls.key, st1) : 0.f;
+        } else {
+          w = row[e];
+          if (need_state) {
+            s0 = kind != MONO_OPT_SGD ? row[st0] : 0.f;
+            s1 = kind == MONO_OPT_FTRL ? row[st1] : 0.f;
+          }
+        }
+      }
+      const int64_t total = ls.end - ls.first;
+      const int64_t ntiles = (total + rows_per_tile - 1) / rows_per_tile;
+      float stage[kStage];
+      auto issue = [&](int64_t tl) {  // gather tile tl into registers
+        const int64_t base = ls.first + tl * rows_per_tile;
+        const int64_t rows = min((int64_t)rows_per_tile, ls.end - base);
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {
+          const int f = k * 256 + tid;
+          const int r = f / D, c = f - r * D;
+          stage[k] = (r < rows) ? a.src[(uint64_t)a.sidx[base + r] * D + c] : 0.f;
+        }
+      };
+      issue(0);
+#pragma unroll
+      for (int k = 0; k < kStage; ++k) tile[0][k * 256 + tid] = stage[k];
+      __syncthreads();
+      bool have_acc = false;
+      for (int64_t tl = 0; tl < ntiles; ++tl) {
+        const int cur = (int)(tl & 1);
+        if (tl + 1 < ntiles) issue(tl + 1);
+        if (owner) {
+          const int64_t base = ls.first + tl * rows_per_tile;
+          const int rows = (int)min((int64_t)rows_per_tile, ls.end - base);
+          const float* tp = &tile[cur][e];  // the tile holds columns [0, D) of each row
+          // LDS reads are issued 16 at a time so their latency overlaps; the adds / steps
+          // below consume them strictly in input order.
+          int r = 0;
+          if (a.mode == MODE_OPT_DEDUP && !have_acc) {
+            acc = tp[0];
+            have_acc = true;
+            r = 1;
+          }
+          for (; r + 16 <= rows; r += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = tp[(r + k) * D];
+            if (a.mode == MODE_ASSIGN_ADD) {
+#pragma unroll
+              for (int k = 0; k < 16; ++k) w += v[k];
+            } else if (a.mode == MODE_OPT_SEQ) {
+#pragma unroll
+              for (int k = 0; k < 16; ++k)
+                opt_step(kind, t.seg[segi], a.lr[segi], v[k], w, s0, s1);
+            } else {
+#pragma unroll
+              for (int k = 0; k < 16; ++k) acc = acc + v[k];
+            }
+          }
+          for (; r < rows; ++r) {
+            const float v = tp[r * D];
+            if (a.mode == MODE_ASSIGN_ADD) w += v;
+            else if (a.mode == MODE_OPT_SEQ) opt_step(kind, t.seg[segi], a.lr[segi], v, w, s0, s1);
+            else acc = acc + v;
+          }
+        }
+        if (tl + 1 < ntiles) {
+#pragma unroll
+          for (int k = 0; k < kStage; ++k) tile[cur ^ 1][k * 256 + tid] = stage[k];
+        }
+        __syncthreads();
+      }
+      if (owner) {
+        if (a.mode == MODE_OPT_DEDUP) opt_step(kind, t.seg[segi], a.lr[segi], acc, w, s0, s1);
+        row[e] = w;
+        if (need_state || ls.fresh) {
+          if (kind != MONO_OPT_SGD) row[st0] = s0;
+          if (kind == MONO_OPT_FTRL) row[st1] = s1;
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) t.ts[ls.slot] = a.ts;
+  }
 }
 
 // D1: cuckoo_embedding_hash_table.cc:220-233. One thread per slot, 12 B (key + ts) per slot.
@@ -700,6 +842,15 @@ static void launch_apply(const Table* t, const ApplyArgs& a, hipStream_t st) {
   if (t->opt_tmpl == OPTK_MULTI || t->vec == 1) launch_apply_v<1>(t, a, st);
   else if (t->vec == 2) launch_apply_v<2>(t, a, st);
   else launch_apply_v<4>(t, a, st);
+  if (a.mode != MODE_ASSIGN_ADD && a.mode != MODE_OPT_SEQ && a.mode != MODE_OPT_DEDUP) return;
+  if (a.n <= kLongSeg) return;
+  const unsigned grid = (unsigned)std::min<int64_t>(a.n / kLongSeg, 1024);
+  switch (t->opt_tmpl) {
+    case OPTK_SGD: hipLaunchKernelGGL(k_apply_long<OPTK_SGD>, dim3(grid), dim3(256), 0, st, t->d, a); break;
+    case OPTK_ADAGRAD: hipLaunchKernelGGL(k_apply_long<OPTK_ADAGRAD>, dim3(grid), dim3(256), 0, st, t->d, a); break;
+    case OPTK_FTRL: hipLaunchKernelGGL(k_apply_long<OPTK_FTRL>, dim3(grid), dim3(256), 0, st, t->d, a); break;
+    default: hipLaunchKernelGGL(k_apply_long<OPTK_MULTI>, dim3(grid), dim3(256), 0, st, t->d, a); break;
+  }
 }
 
 static int bits_for(uint64_t max_value) {
@@ -732,6 +883,9 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
 
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
+  const size_t q_bytes = 256 + ((size_t)n / kLongSeg + 1) * sizeof(LongSeg);
+  char* q_base = nullptr;
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev[0], st));
   if (!from_keys) {
     // (slot, idx) pairs -> stable radix sort on the bits a slot can occupy
     size_t tmp_bytes = 0;
@@ -740,8 +894,9 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
                                        (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0,
                                        end_bit, st));
     tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
-    MONO_TRY(t->ws.ensure(4 * n_al * sizeof(uint32_t) + tmp_bytes));
+    MONO_TRY(t->ws.ensure(4 * n_al * sizeof(uint32_t) + tmp_bytes + q_bytes));
     uint32_t* slot_in = (uint32_t*)t->ws.ptr;
+    q_base = (char*)t->ws.ptr + 4 * n_al * sizeof(uint32_t) + tmp_bytes;
     uint32_t* idx_in = slot_in + n_al;
     uint32_t* slot_out = idx_in + n_al;
     uint32_t* idx_out = slot_out + n_al;
@@ -749,6 +904,7 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
     hipLaunchKernelGGL(k_find_or_claim, dim3(grid_for(n, 32)), dim3(256), 0, st, t->d, ids, n,
                        slot_in, idx_in);
     MONO_HIP(hipGetLastError());
+    if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
     MONO_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, slot_in, slot_out, idx_in, idx_out,
                                        (size_t)n, 0, end_bit, st));
     a.skeys = slot_out;
@@ -758,19 +914,26 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
     MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (int64_t*)nullptr, (int64_t*)nullptr,
                                        (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 64, st));
     tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
-    MONO_TRY(t->ws.ensure(n_al * sizeof(int64_t) + 2 * n_al * sizeof(uint32_t) + tmp_bytes));
+    MONO_TRY(t->ws.ensure(n_al * sizeof(int64_t) + 2 * n_al * sizeof(uint32_t) + tmp_bytes + q_bytes));
     int64_t* key_out = (int64_t*)t->ws.ptr;
+    q_base = (char*)t->ws.ptr + n_al * sizeof(int64_t) + 2 * n_al * sizeof(uint32_t) + tmp_bytes;
     uint32_t* idx_in = (uint32_t*)(key_out + n_al);
     uint32_t* idx_out = idx_in + n_al;
     void* tmp = idx_out + n_al;
     hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 256)), dim3(256), 0, st, idx_in, n);
+    if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
     MONO_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, ids, key_out, idx_in, idx_out, (size_t)n, 0,
                                        64, st));
     a.skeys = key_out;
     a.sidx = idx_out;
   }
+  a.qcount = (uint32_t*)q_base;
+  a.queue = (LongSeg*)(q_base + 256);
+  MONO_HIP(hipMemsetAsync(a.qcount, 0, sizeof(uint32_t), st));
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev[2], st));
   launch_apply(t, a, st);
   MONO_HIP(hipGetLastError());
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
   if (from_keys) MONO_TRY(filter_after_batch(filter, st));
   return 0;
 }
@@ -785,6 +948,12 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
   MONO_REQUIRE(cfg && out_table, "mono_table_create: null argument");
   MONO_REQUIRE(cfg->n_segments >= 1 && cfg->n_segments <= kMaxSeg,
                "mono_table_create: %d segments (supported: 1..%d)", cfg->n_segments, kMaxSeg);
+  {
+    int64_t total_dim = 0;
+    for (int s = 0; s < cfg->n_segments; ++s) total_dim += cfg->segments[s].dim;
+    MONO_REQUIRE(total_dim <= kTileFloats, "mono_table_create: dim %lld exceeds %d",
+                 (long long)total_dim, kTileFloats);
+  }
   Table* t = new Table();
   int w = 0;
   for (int s = 0; s < cfg->n_segments; ++s) {
@@ -850,7 +1019,27 @@ int mono_table_destroy(void* table) {
   free_arrays(&t->d);
   if (t->slot_expire_dev) (void)hipFree(t->slot_expire_dev);
   t->ws.release();
+  for (int i = 0; i < 4; ++i)
+    if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
   delete t;
+  return 0;
+}
+
+int mono_table_profile(void* table, int enable) {
+  MONO_REQUIRE(table, "mono_table_profile: null table");
+  Table* t = (Table*)table;
+  if (enable && !t->ev[0])
+    for (int i = 0; i < 4; ++i) MONO_HIP(hipEventCreate(&t->ev[i]));
+  t->profile = enable != 0;
+  return 0;
+}
+
+int mono_table_last_phase_ms(void* table, float* h_ms) {
+  MONO_REQUIRE(table && h_ms, "mono_table_last_phase_ms: null argument");
+  Table* t = (Table*)table;
+  MONO_REQUIRE(t->profile && t->ev[0], "mono_table_last_phase_ms: profiling is off");
+  MONO_HIP(hipEventSynchronize(t->ev[3]));
+  for (int i = 0; i < 3; ++i) MONO_HIP(hipEventElapsedTime(&h_ms[i], t->ev[i], t->ev[i + 1]));
   return 0;
 }
 
