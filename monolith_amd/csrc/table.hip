@@ -72,6 +72,9 @@ struct Table {
   // optional per-phase timing of the write path (mono_table_profile)
   bool profile = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // fork / join of the long-segment kernel beside the sub-group kernel
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -285,15 +288,32 @@ struct ApplyArgs {
   FilterDev filt;  // from_keys only; filt.kind == 0 -> no gate
   int assign_add_semantics;  // filter gate of the per-id AssignAdd loop (bridge :186-209)
   struct LongSeg* queue;     // segments longer than kLongSeg, drained by k_apply_long
-  uint32_t* qcount;
+  uint32_t* qcount;          // [0] queue entries [1] compacted heads [2] split keys [3] partial rows
+  struct SplitSeg* cqueue;   // keys whose segment was cut into chunks, finished by k_combine
+  float* partials;           // [partial row][dim] chunk sums of the split keys
+  const uint2* heads;        // compacted (position, length) of the short segments, or nullptr
+  const uint32_t* nheads;
 };
 
 // A key with many occurrences in one batch (a Zipf head): handed to a whole workgroup.
 struct LongSeg {
   int64_t first, end, key;
   uint32_t slot, fresh;
+  uint32_t part;  // partial-row index when this entry is one chunk of a split key, else kNoPart
+  uint32_t pad;
 };
+struct SplitSeg {
+  int64_t key;
+  uint32_t slot, fresh, pbase, nparts;
+};
+constexpr uint32_t kNoPart = 0xFFFFFFFFu;
 constexpr int kLongSeg = 96;       // occurrences above which a segment goes to k_apply_long
+// A key with more than kChunk occurrences in one batch is summed in near-equal chunks of at most
+// kChunk occurrences (each chunk in input order, by its own workgroup); k_combine then adds the
+// chunk sums in chunk order. This is the one place the summation order differs from the
+// sequential reference (DESIGN.md "hot keys"); MODE_OPT_SEQ is never split.
+constexpr int kChunk = 4096;
+constexpr int kLongMaxDim = 512;   // wider rows stay on the sub-group path
 constexpr int kTileFloats = 2048;  // LDS staging tile (8 KB), double buffered
 
 template <typename K>
@@ -337,30 +357,73 @@ __device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, fl
   }
 }
 
+__device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t end, int64_t key,
+                                    uint32_t slot, uint32_t fresh) {
+  const int64_t len = end - first;
+  const bool split = a.mode != MODE_OPT_SEQ && len > kChunk;
+  const uint32_t nparts = split ? (uint32_t)((len + kChunk - 1) / kChunk) : 1u;
+  const int64_t csz = (len + nparts - 1) / nparts;
+  const uint32_t q = atomicAdd(&a.qcount[0], nparts);
+  uint32_t pbase = kNoPart;
+  if (split) {
+    pbase = atomicAdd(&a.qcount[3], nparts);
+    const uint32_t c = atomicAdd(&a.qcount[2], 1u);
+    SplitSeg sp;
+    sp.key = key; sp.slot = slot; sp.fresh = fresh; sp.pbase = pbase; sp.nparts = nparts;
+    a.cqueue[c] = sp;
+  }
+  for (uint32_t p = 0; p < nparts; ++p) {
+    LongSeg ls;
+    ls.first = first + (int64_t)p * csz;
+    ls.end = min(end, ls.first + csz);
+    ls.key = key; ls.slot = slot; ls.fresh = fresh;
+    ls.part = split ? pbase + p : kNoPart;
+    ls.pad = 0;
+    a.queue[q + p] = ls;
+  }
+}
+
 // Write path, step 2: one 8-lane sub-group per distinct key walks that key's occurrences in
 // input order (the sort is stable) with the row chunk held in registers, then stores row + ts.
 // B3/B4: bridge :156-313, cuckoo_embedding_hash_table.cc:174-216, entry_accessor.cc:149-171.
 template <int V, int OPTK>
 __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
   const int sub = lane_sub(), gshift = lane_gshift();
-  const int64_t j = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
+  int64_t j = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
   if (j >= a.n) return;
   const int D = t.dim, R = t.row_floats;
+  uint2 hd = make_uint2(0u, 0u);
+  if (a.heads) {  // compacted segment heads (k_classify): every sub-group has work
+    if (j >= (int64_t)*a.nheads) return;
+    hd = a.heads[j];
+    j = hd.x;
+  }
 
   uint32_t slot;
   int64_t end;
   int64_t first = j;  // first occurrence (sorted position) that is applied
   bool fresh = false; // row claimed here and not yet initialised in memory
   int64_t key = 0;
+  uint32_t idx0 = 0;  // occurrence index of sorted position j
   if (!a.from_keys) {
     const uint32_t* sk = static_cast<const uint32_t*>(a.skeys);
+    // four independent loads up front: the common single-occurrence segment then needs only
+    // two dependent memory levels (sorted arrays -> row + gradient)
     slot = sk[j];
-    if (j > 0 && sk[j - 1] == slot) return;
-    if (slot == kNoSlot) return;
-    end = segment_end<uint32_t>(sk, j, a.n, slot);
+    idx0 = a.sidx[j];
+    if (a.heads) {
+      end = j + hd.y;
+    } else {
+      const uint32_t prev = j > 0 ? sk[j - 1] : ~slot;
+      const uint32_t next = j + 1 < a.n ? sk[j + 1] : ~slot;
+      if (prev == slot) return;
+      if (slot == kNoSlot) return;
+      end = next != slot ? j + 1 : segment_end<uint32_t>(sk, j, a.n, slot);
+    }
   } else {
     const int64_t* sk = static_cast<const int64_t*>(a.skeys);
     key = sk[j];
+    idx0 = a.sidx[j];
     if (j > 0 && sk[j - 1] == key) return;
     end = segment_end<int64_t>(sk, j, a.n, key);
     slot = group_find(t, key, sub, gshift);
@@ -404,14 +467,9 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
     }
   }
 
-  if (end - first > kLongSeg &&
+  if (end - first > kLongSeg && D <= kLongMaxDim &&
       (a.mode == MODE_ASSIGN_ADD || a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP)) {
-    if (sub == 0) {
-      uint32_t q = atomicAdd(a.qcount, 1u);
-      LongSeg ls;
-      ls.first = first; ls.end = end; ls.key = key; ls.slot = slot; ls.fresh = fresh;
-      a.queue[q] = ls;
-    }
+    if (sub == 0) enqueue_long(a, first, end, key, slot, fresh ? 1u : 0u);
     return;
   }
 
@@ -490,7 +548,7 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
       }
     } else {  // MODE_OPT_DEDUP: in-order sum (bridge :251-266), then one step
       float acc[V];
-      vload<V>(acc, a.src + (uint64_t)a.sidx[first] * D + e0);
+      vload<V>(acc, a.src + (uint64_t)(first == j ? idx0 : a.sidx[first]) * D + e0);
       int64_t p = first + 1;
       for (; p + 4 <= end; p += 4) {  // 4 independent loads in flight, adds stay in order
         float g0[V], g1[V], g2[V], g3[V];
@@ -528,24 +586,97 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
   if (sub == 0) t.ts[slot] = a.ts;
 }
 
-// Long segments: one 256-thread workgroup per key. All threads gather the next tile of
-// occurrence rows (coalesced 64 B+ pieces) while thread e < dim walks the current tile out of
-// LDS, so the adds / optimizer steps stay in input order (bit-exact with the sequential
-// reference) and the gather latency hides behind the dependent chain.
-template <int OPTK>
+// Segment classification (no-filter path): kClsItems sorted positions per thread. Segment heads
+// are compacted into `heads` (so the sub-group kernel has no idle groups) or, when longer than
+// kLongSeg in a walking mode, pushed to the long-segment queue. Head slots are handed out
+// through an LDS counter and ONE global atomic per workgroup: a device-scope atomic on a single
+// word retires at only ~90 per microsecond, so a per-wave atomic would cost more than the sort.
+constexpr int kClsThreads = 1024;
+constexpr int kClsItems = 4;
+__global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow_long,
+                                                          uint2* __restrict__ heads) {
+  __shared__ uint32_t s_cnt, s_base;
+  const uint32_t* __restrict__ sk = static_cast<const uint32_t*>(a.skeys);
+  const int64_t n = a.n;
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * (kClsThreads * kClsItems);
+  uint32_t loc[kClsItems], len[kClsItems];
+  bool sh[kClsItems];
+#pragma unroll
+  for (int k = 0; k < kClsItems; ++k) {
+    const int64_t j = base + (int64_t)k * kClsThreads + tid;
+    sh[k] = false;
+    len[k] = 1;
+    loc[k] = 0;
+    if (j < n) {
+      const uint32_t slot = sk[j];
+      const uint32_t prev = j > 0 ? sk[j - 1] : ~slot;
+      const uint32_t next = j + 1 < n ? sk[j + 1] : ~slot;
+      if (prev != slot && slot != kNoSlot) {
+        if (next == slot) len[k] = (uint32_t)(segment_end<uint32_t>(sk, j, n, slot) - j);
+        if (allow_long && len[k] > (uint32_t)kLongSeg)
+          enqueue_long(a, j, j + len[k], 0, slot, 0u);
+        else
+          sh[k] = true;
+      }
+    }
+    const unsigned long long m = __ballot(sh[k]);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      uint32_t wb = 0;
+      if (lane == leader) wb = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+      wb = __shfl(wb, leader);
+      loc[k] = wb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+  }
+  __syncthreads();
+  if (tid == 0) s_base = s_cnt ? atomicAdd(&a.qcount[1], s_cnt) : 0u;
+  __syncthreads();
+  const uint32_t gb = s_base;
+#pragma unroll
+  for (int k = 0; k < kClsItems; ++k)
+    if (sh[k])
+      heads[gb + loc[k]] = make_uint2((uint32_t)(base + (int64_t)k * kClsThreads + tid), len[k]);
+}
+
+// Long segments: one 256-thread workgroup per key, split into roles. Waves 1-3 (192 loader
+// threads) gather occurrence rows two tiles ahead (register staging -> LDS; occurrence indices
+// are prefetched through an LDS ring so a row load never waits on an index load) and store
+// them COLUMN-major. Wave 0 only consumes: lane e reads column e four rows per ds_read_b128
+// and adds / steps in input order — bit-exact with the sequential reference. A lone wave
+// issues one VALU op per ~4 cycles, so the walk is kept at ~1.5 instructions per row; what is
+// left is the dependent floating-point chain itself.
+constexpr int kLoaders = 192;
+constexpr int kLStage = 32;                 // floats staged per loader thread per tile
+constexpr int kLTile = kLoaders * kLStage;  // 6144 floats (24 KB) per tile
+constexpr int kLMaxRows = 2 * kLoaders;     // two prefetched indices per loader thread
+constexpr int kLPad = 4;                    // column stride = rows + 4 floats (16 B aligned)
+constexpr int kLBuf = kLTile + 64 * kLPad + 64;
+
+template <int OPTK, int MODE>
 __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
-  __shared__ float tile[2][kTileFloats];
+  __shared__ __attribute__((aligned(16))) float tile[2][kLBuf];
+  __shared__ uint32_t idxs[4][kLMaxRows];
   const int D = t.dim, R = t.row_floats;
   const int tid = threadIdx.x;
-  const int rows_per_tile = kTileFloats / D;  // host guarantees D <= kTileFloats
+  const bool loader = tid >= 64;
+  const int lt = tid - 64;  // loader thread index
+  // rows per tile: a multiple of 4 (b128 reads), one index per loader thread
+  const int rpt = max(4, min(kLMaxRows, kLTile / D) & ~3);
+  const int cs = rpt + kLPad;  // column stride in floats
+  // loader element walk: f = k * kLoaders + lt -> (row, column) without per-element division
+  const int r0 = loader ? lt / D : 0, c0 = loader ? lt - r0 * D : 0;
+  const int dr = kLoaders / D, dc = kLoaders - dr * D;
   const uint32_t nq = *a.qcount;
-  constexpr int kStage = kTileFloats / 256;
   for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
     const LongSeg ls = a.queue[qi];
     float* row = t.rows + (uint64_t)ls.slot * R;
-    for (int eb = 0; eb < D; eb += 256) {  // element blocks (one pass for dim <= 256)
+    const int64_t ntiles = (ls.end - ls.first + rpt - 1) / rpt;
+    for (int eb = 0; eb < D; eb += 64) {  // 64 columns per pass (one pass for dim <= 64)
       const int e = eb + tid;
-      const bool owner = e < D;
+      const bool owner = !loader && e < D;
       int kind = OPTK, segi = 0, st0 = D + e, st1 = 2 * D + e;
       if (OPTK == OPTK_MULTI && owner) {
         for (int z = 0; z < t.n_seg; ++z)
@@ -555,8 +686,10 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         st1 = st0 + t.seg[segi].dim;
       }
       float w = 0.f, s0 = 0.f, s1 = 0.f, acc = 0.f;
-      const bool need_state = a.mode >= MODE_OPT_SEQ;
-      if (owner) {
+      bool have_acc = false;
+      const bool need_state = MODE >= MODE_OPT_SEQ;
+      const bool part = ls.part != kNoPart;  // one chunk of a split key: emit the chunk sum only
+      if (owner && !part) {
         if (ls.fresh) {
           w = row_init_value(t, ls.key, e);
           s0 = kind != MONO_OPT_SGD ? row_init_value(t, ls.key, st0) : 0.f;
@@ -569,79 +702,196 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
           }
         }
       }
-      const int64_t total = ls.end - ls.first;
-      const int64_t ntiles = (total + rows_per_tile - 1) / rows_per_tile;
-      float stage[kStage];
-      auto issue = [&](int64_t tl) {  // gather tile tl into registers
-        const int64_t base = ls.first + tl * rows_per_tile;
-        const int64_t rows = min((int64_t)rows_per_tile, ls.end - base);
+      const SegDev& sg = t.seg[segi];
+      const float lr = a.lr[segi];
+      auto load_idx = [&](int64_t tl, int half) -> uint32_t {
+        const int rr = lt + half * kLoaders;
+        const int64_t p = ls.first + tl * rpt + rr;
+        return (loader && rr < rpt && p < ls.end) ? a.sidx[p] : 0u;
+      };
+      auto issue = [&](float(&S)[kLStage], int64_t tl) {  // loaders: gather tile tl into registers
+        if (!loader || tl >= ntiles) return;
+        const int rows = (int)min((int64_t)rpt, ls.end - (ls.first + tl * rpt));
+        const uint32_t* ix = idxs[tl & 3];
+        int r = r0, c = c0;
 #pragma unroll
-        for (int k = 0; k < kStage; ++k) {
-          const int f = k * 256 + tid;
-          const int r = f / D, c = f - r * D;
-          stage[k] = (r < rows) ? a.src[(uint64_t)a.sidx[base + r] * D + c] : 0.f;
+        for (int k = 0; k < kLStage; ++k) {
+          S[k] = (r < rows) ? a.src[(uint64_t)ix[r] * D + c] : 0.f;
+          r += dr;
+          c += dc;
+          if (c >= D) { c -= D; ++r; }
         }
       };
-      issue(0);
+      auto put = [&](const float(&S)[kLStage], int buf) {  // column-major store of columns [eb, eb+64)
+        if (!loader) return;
+        int r = r0, c = c0;
 #pragma unroll
-      for (int k = 0; k < kStage; ++k) tile[0][k * 256 + tid] = stage[k];
-      __syncthreads();
-      bool have_acc = false;
-      for (int64_t tl = 0; tl < ntiles; ++tl) {
-        const int cur = (int)(tl & 1);
-        if (tl + 1 < ntiles) issue(tl + 1);
-        if (owner) {
-          const int64_t base = ls.first + tl * rows_per_tile;
-          const int rows = (int)min((int64_t)rows_per_tile, ls.end - base);
-          const float* tp = &tile[cur][e];  // the tile holds columns [0, D) of each row
-          // LDS reads are issued 16 at a time so their latency overlaps; the adds / steps
-          // below consume them strictly in input order.
-          int r = 0;
-          if (a.mode == MODE_OPT_DEDUP && !have_acc) {
-            acc = tp[0];
-            have_acc = true;
-            r = 1;
-          }
-          for (; r + 16 <= rows; r += 16) {
-            float v[16];
+        for (int k = 0; k < kLStage; ++k) {
+          const int cc = c - eb;
+          if (r < rpt && cc >= 0 && cc < 64) tile[buf][cc * cs + r] = S[k];
+          r += dr;
+          c += dc;
+          if (c >= D) { c -= D; ++r; }
+        }
+      };
+      auto compute = [&](int64_t tl, int buf) {  // wave 0: walk the tile in input order
+        if (!owner) return;
+        const int rows = (int)min((int64_t)rpt, ls.end - (ls.first + tl * rpt));
+        const float* tp = &tile[buf][tid * cs];
+        int r = 0;
+        if (MODE == MODE_OPT_DEDUP && !have_acc) {  // first row seeds the sum
+          const float4 q = *reinterpret_cast<const float4*>(tp);
+          acc = q.x;
+          if (rows > 1) acc = acc + q.y;
+          if (rows > 2) acc = acc + q.z;
+          if (rows > 3) acc = acc + q.w;
+          have_acc = true;
+          r = 4;
+        }
+        // 16 rows per step, software pipelined: the next step's four ds_read_b128 are in
+        // flight while the current 16 values are consumed.
+        auto consume = [&](const float4(&q)[4]) {
+          if (MODE == MODE_OPT_DEDUP) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = tp[(r + k) * D];
-            if (a.mode == MODE_ASSIGN_ADD) {
+            for (int k = 0; k < 4; ++k) acc = (((acc + q[k].x) + q[k].y) + q[k].z) + q[k].w;
+          } else if (MODE == MODE_ASSIGN_ADD) {
 #pragma unroll
-              for (int k = 0; k < 16; ++k) w += v[k];
-            } else if (a.mode == MODE_OPT_SEQ) {
+            for (int k = 0; k < 4; ++k) w = (((w + q[k].x) + q[k].y) + q[k].z) + q[k].w;
+          } else {
 #pragma unroll
-              for (int k = 0; k < 16; ++k)
-                opt_step(kind, t.seg[segi], a.lr[segi], v[k], w, s0, s1);
-            } else {
-#pragma unroll
-              for (int k = 0; k < 16; ++k) acc = acc + v[k];
+            for (int k = 0; k < 4; ++k) {
+              opt_step(kind, sg, lr, q[k].x, w, s0, s1);
+              opt_step(kind, sg, lr, q[k].y, w, s0, s1);
+              opt_step(kind, sg, lr, q[k].z, w, s0, s1);
+              opt_step(kind, sg, lr, q[k].w, w, s0, s1);
             }
           }
-          for (; r < rows; ++r) {
-            const float v = tp[r * D];
-            if (a.mode == MODE_ASSIGN_ADD) w += v;
-            else if (a.mode == MODE_OPT_SEQ) opt_step(kind, t.seg[segi], a.lr[segi], v, w, s0, s1);
-            else acc = acc + v;
+        };
+        if (r + 16 <= rows) {
+          float4 qa[4], qb[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) qa[k] = *reinterpret_cast<const float4*>(tp + r + 4 * k);
+          for (;;) {
+            const bool more_b = r + 32 <= rows;
+            if (more_b) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) qb[k] = *reinterpret_cast<const float4*>(tp + r + 16 + 4 * k);
+            }
+            consume(qa);
+            r += 16;
+            if (!more_b) break;
+            const bool more_a = r + 32 <= rows;
+            if (more_a) {
+#pragma unroll
+              for (int k = 0; k < 4; ++k) qa[k] = *reinterpret_cast<const float4*>(tp + r + 16 + 4 * k);
+            }
+            consume(qb);
+            r += 16;
+            if (!more_a) break;
           }
         }
-        if (tl + 1 < ntiles) {
-#pragma unroll
-          for (int k = 0; k < kStage; ++k) tile[cur ^ 1][k * 256 + tid] = stage[k];
+        for (; r < rows; ++r) {
+          const float v = tp[r];
+          if (MODE == MODE_ASSIGN_ADD) w += v;
+          else if (MODE == MODE_OPT_SEQ) opt_step(kind, sg, lr, v, w, s0, s1);
+          else acc = acc + v;
         }
+      };
+
+      __syncthreads();  // LDS of the previous segment / element block is free
+      if (loader) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          idxs[0][lt + h * kLoaders] = load_idx(0, h);
+          idxs[1][lt + h * kLoaders] = load_idx(1, h);
+          idxs[2][lt + h * kLoaders] = load_idx(2, h);
+        }
+      }
+      __syncthreads();
+      // One register stage: a round first parks the tile fetched during the previous round
+      // (its loads had a whole consumer round to land), then issues the next gather. Index
+      // prefetch runs one round further ahead (loaded in round t, parked in round t + 1).
+      float S[kLStage];
+      uint32_t nx0 = load_idx(3, 0), nx1 = load_idx(3, 1);
+      issue(S, 0);
+      put(S, 0);
+      issue(S, 1);
+      __syncthreads();
+      for (int64_t tl = 0; tl < ntiles; ++tl) {
+        // tile tl sits in LDS[tl & 1]; S carries tile tl + 1
+        const int cur = (int)(tl & 1);
+        if (tl + 1 < ntiles) put(S, cur ^ 1);
+        if (loader) {
+          idxs[(tl + 3) & 3][lt] = nx0;
+          idxs[(tl + 3) & 3][lt + kLoaders] = nx1;
+        }
+        nx0 = load_idx(tl + 4, 0);
+        nx1 = load_idx(tl + 4, 1);
+        issue(S, tl + 2);
+        compute(tl, cur);
         __syncthreads();
       }
-      if (owner) {
-        if (a.mode == MODE_OPT_DEDUP) opt_step(kind, t.seg[segi], a.lr[segi], acc, w, s0, s1);
+      if (owner && part) {
+        a.partials[(uint64_t)ls.part * D + e] = MODE == MODE_ASSIGN_ADD ? w : acc;
+      } else if (owner) {
+        if (MODE == MODE_OPT_DEDUP) opt_step(kind, sg, lr, acc, w, s0, s1);
         row[e] = w;
         if (need_state || ls.fresh) {
           if (kind != MONO_OPT_SGD) row[st0] = s0;
           if (kind == MONO_OPT_FTRL) row[st1] = s1;
         }
       }
-      __syncthreads();
     }
-    if (tid == 0) t.ts[ls.slot] = a.ts;
+    if (tid == 0 && ls.part == kNoPart) t.ts[ls.slot] = a.ts;
+  }
+}
+
+// Split keys: add the chunk sums in chunk order, then finish like an unsplit segment. One wave
+// per key, lane e owns column e.
+template <int OPTK>
+__global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
+  const int D = t.dim, R = t.row_floats;
+  const uint32_t nc = a.qcount[2];
+  for (uint32_t ci = blockIdx.x; ci < nc; ci += gridDim.x) {
+    const SplitSeg sp = a.cqueue[ci];
+    float* row = t.rows + (uint64_t)sp.slot * R;
+    for (int e = threadIdx.x; e < D; e += 64) {
+      int kind = OPTK, segi = 0, st0 = D + e, st1 = 2 * D + e;
+      if (OPTK == OPTK_MULTI) {
+        for (int z = 0; z < t.n_seg; ++z)
+          if (e >= t.seg[z].w_off && e < t.seg[z].w_off + t.seg[z].dim) segi = z;
+        kind = t.seg[segi].opt_kind;
+        st0 = t.seg[segi].st_off + (e - t.seg[segi].w_off);
+        st1 = st0 + t.seg[segi].dim;
+      }
+      const bool need_state = a.mode >= MODE_OPT_SEQ;
+      float w, s0 = 0.f, s1 = 0.f;
+      if (sp.fresh) {
+        w = row_init_value(t, sp.key, e);
+        s0 = kind != MONO_OPT_SGD ? row_init_value(t, sp.key, st0) : 0.f;
+        s1 = kind == MONO_OPT_FTRL ? row_init_value(t, sp.key, st1) : 0.f;
+      } else {
+        w = row[e];
+        if (need_state) {
+          s0 = kind != MONO_OPT_SGD ? row[st0] : 0.f;
+          s1 = kind == MONO_OPT_FTRL ? row[st1] : 0.f;
+        }
+      }
+      const float* pp = a.partials + (uint64_t)sp.pbase * D + e;
+      if (a.mode == MODE_ASSIGN_ADD) {
+        for (uint32_t p = 0; p < sp.nparts; ++p) w += pp[(uint64_t)p * D];
+      } else {
+        float acc = pp[0];
+        for (uint32_t p = 1; p < sp.nparts; ++p) acc = acc + pp[(uint64_t)p * D];
+        opt_step(kind, t.seg[segi], a.lr[segi], acc, w, s0, s1);
+      }
+      row[e] = w;
+      if (need_state || sp.fresh) {
+        if (kind != MONO_OPT_SGD) row[st0] = s0;
+        if (kind == MONO_OPT_FTRL) row[st1] = s1;
+      }
+    }
+    if (threadIdx.x == 0) t.ts[sp.slot] = a.ts;
   }
 }
 
@@ -838,19 +1088,81 @@ static void launch_apply_v(const Table* t, const ApplyArgs& a, hipStream_t st) {
     default: launch_apply_vo<1, OPTK_MULTI>(t, a, st); break;
   }
 }
-static void launch_apply(const Table* t, const ApplyArgs& a, hipStream_t st) {
+template <int OPTK>
+static void launch_long_m(const Table* t, const ApplyArgs& a, unsigned grid, hipStream_t st) {
+  switch (a.mode) {
+    case MODE_ASSIGN_ADD:
+      hipLaunchKernelGGL((k_apply_long<OPTK, MODE_ASSIGN_ADD>), dim3(grid), dim3(256), 0, st, t->d, a);
+      break;
+    case MODE_OPT_SEQ:
+      hipLaunchKernelGGL((k_apply_long<OPTK, MODE_OPT_SEQ>), dim3(grid), dim3(256), 0, st, t->d, a);
+      break;
+    default:
+      hipLaunchKernelGGL((k_apply_long<OPTK, MODE_OPT_DEDUP>), dim3(grid), dim3(256), 0, st, t->d, a);
+      break;
+  }
+}
+static void launch_long_o(const Table* t, const ApplyArgs& a, unsigned grid, hipStream_t st) {
+  const unsigned cgrid = (unsigned)std::min<int64_t>(a.n / kChunk + 1, 256);
+  const bool may_split = a.mode != MODE_OPT_SEQ && a.n > kChunk;
+  switch (t->opt_tmpl) {
+    case OPTK_SGD:
+      launch_long_m<OPTK_SGD>(t, a, grid, st);
+      if (may_split) hipLaunchKernelGGL(k_combine<OPTK_SGD>, dim3(cgrid), dim3(64), 0, st, t->d, a);
+      break;
+    case OPTK_ADAGRAD:
+      launch_long_m<OPTK_ADAGRAD>(t, a, grid, st);
+      if (may_split) hipLaunchKernelGGL(k_combine<OPTK_ADAGRAD>, dim3(cgrid), dim3(64), 0, st, t->d, a);
+      break;
+    case OPTK_FTRL:
+      launch_long_m<OPTK_FTRL>(t, a, grid, st);
+      if (may_split) hipLaunchKernelGGL(k_combine<OPTK_FTRL>, dim3(cgrid), dim3(64), 0, st, t->d, a);
+      break;
+    default:
+      launch_long_m<OPTK_MULTI>(t, a, grid, st);
+      if (may_split) hipLaunchKernelGGL(k_combine<OPTK_MULTI>, dim3(cgrid), dim3(64), 0, st, t->d, a);
+      break;
+  }
+}
+static void launch_short(const Table* t, const ApplyArgs& a, hipStream_t st) {
   if (t->opt_tmpl == OPTK_MULTI || t->vec == 1) launch_apply_v<1>(t, a, st);
   else if (t->vec == 2) launch_apply_v<2>(t, a, st);
   else launch_apply_v<4>(t, a, st);
-  if (a.mode != MODE_ASSIGN_ADD && a.mode != MODE_OPT_SEQ && a.mode != MODE_OPT_DEDUP) return;
-  if (a.n <= kLongSeg) return;
-  const unsigned grid = (unsigned)std::min<int64_t>(a.n / kLongSeg, 1024);
-  switch (t->opt_tmpl) {
-    case OPTK_SGD: hipLaunchKernelGGL(k_apply_long<OPTK_SGD>, dim3(grid), dim3(256), 0, st, t->d, a); break;
-    case OPTK_ADAGRAD: hipLaunchKernelGGL(k_apply_long<OPTK_ADAGRAD>, dim3(grid), dim3(256), 0, st, t->d, a); break;
-    case OPTK_FTRL: hipLaunchKernelGGL(k_apply_long<OPTK_FTRL>, dim3(grid), dim3(256), 0, st, t->d, a); break;
-    default: hipLaunchKernelGGL(k_apply_long<OPTK_MULTI>, dim3(grid), dim3(256), 0, st, t->d, a); break;
+}
+
+static int launch_apply(Table* t, ApplyArgs& a, uint2* heads, uint32_t* nheads, hipStream_t st) {
+  const bool walks =
+      a.mode == MODE_ASSIGN_ADD || a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP;
+  const bool allow_long = walks && a.n > kLongSeg && t->d.dim <= kLongMaxDim;
+  const unsigned lgrid = (unsigned)std::min<int64_t>(a.n / kLongSeg + 1, 1024);
+  if (a.from_keys) {
+    // filter path: the sub-group kernel resolves / gates / claims and feeds the long queue
+    launch_short(t, a, st);
+    if (allow_long) launch_long_o(t, a, lgrid, st);
+    return 0;
   }
+  const int64_t per_block = (int64_t)kClsThreads * kClsItems;
+  hipLaunchKernelGGL(k_classify, dim3((unsigned)((a.n + per_block - 1) / per_block)),
+                     dim3(kClsThreads), 0, st, a, allow_long ? 1 : 0, heads);
+  a.heads = heads;
+  a.nheads = nheads;
+  if (!allow_long) {
+    launch_short(t, a, st);
+    return 0;
+  }
+  // long segments are latency-bound on a few CUs: run them beside the sub-group kernel
+  if (!t->aux) {
+    MONO_HIP(hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking));
+    MONO_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+    MONO_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+  }
+  MONO_HIP(hipEventRecord(t->ev_fork, st));
+  MONO_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
+  launch_long_o(t, a, lgrid, t->aux);
+  MONO_HIP(hipEventRecord(t->ev_join, t->aux));
+  launch_short(t, a, st);
+  MONO_HIP(hipStreamWaitEvent(st, t->ev_join, 0));
+  return 0;
 }
 
 static int bits_for(uint64_t max_value) {
@@ -883,7 +1195,10 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
 
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
-  const size_t q_bytes = 256 + ((size_t)n / kLongSeg + 1) * sizeof(LongSeg);
+  const size_t lq_bytes = (((size_t)n / kLongSeg + 2) * sizeof(LongSeg) + 255) & ~(size_t)255;
+  const size_t cq_bytes = (((size_t)n / kChunk + 2) * sizeof(SplitSeg) + 255) & ~(size_t)255;
+  const size_t pt_bytes = (((size_t)n / (kChunk / 2) + 2) * t->d.dim * sizeof(float) + 255) & ~(size_t)255;
+  const size_t q_bytes = 256 + lq_bytes + cq_bytes + pt_bytes + n_al * sizeof(uint2);
   char* q_base = nullptr;
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[0], st));
   if (!from_keys) {
@@ -929,9 +1244,12 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   }
   a.qcount = (uint32_t*)q_base;
   a.queue = (LongSeg*)(q_base + 256);
-  MONO_HIP(hipMemsetAsync(a.qcount, 0, sizeof(uint32_t), st));
+  a.cqueue = (SplitSeg*)(q_base + 256 + lq_bytes);
+  a.partials = (float*)(q_base + 256 + lq_bytes + cq_bytes);
+  uint2* heads = (uint2*)(q_base + 256 + lq_bytes + cq_bytes + pt_bytes);
+  MONO_HIP(hipMemsetAsync(a.qcount, 0, 4 * sizeof(uint32_t), st));
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[2], st));
-  launch_apply(t, a, st);
+  MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st));
   MONO_HIP(hipGetLastError());
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
   if (from_keys) MONO_TRY(filter_after_batch(filter, st));
@@ -984,7 +1302,14 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
   d.seed = cfg->seed;
   d.default_expire_days = cfg->default_expire_days;
   t->opt_tmpl = cfg->n_segments == 1 ? cfg->segments[0].opt_kind : OPTK_MULTI;
-  t->vec = (cfg->n_segments == 1) ? (w % 4 == 0 ? 4 : w % 2 == 0 ? 2 : 1) : 1;
+  // floats per lane: the widest access that still keeps all 8 lanes of a sub-group busy
+  t->vec = 1;
+  if (cfg->n_segments == 1) {
+    if (w % 32 == 0) t->vec = 4;
+    else if (w % 16 == 0) t->vec = 2;
+    else if (w % 8 == 0) t->vec = 1;
+    else t->vec = w % 4 == 0 ? 4 : w % 2 == 0 ? 2 : 1;
+  }
   if (cfg->n_slot_expire > 0) {
     std::vector<int32_t> tbl(1 << 15, cfg->default_expire_days);
     for (int i = 0; i < cfg->n_slot_expire; ++i)
@@ -1021,6 +1346,9 @@ int mono_table_destroy(void* table) {
   t->ws.release();
   for (int i = 0; i < 4; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
+  if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+  if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+  if (t->aux) (void)hipStreamDestroy(t->aux);
   delete t;
   return 0;
 }

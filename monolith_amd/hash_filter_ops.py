@@ -38,8 +38,9 @@ class HashFilter:
 
   def __del__(self):
     h = getattr(self, "_h", None)
-    if h:
-      _lib.lib.mono_filter_destroy(h)
+    lib = getattr(_lib, "lib", None) if _lib is not None else None  # None at interpreter exit
+    if h and lib is not None:
+      lib.mono_filter_destroy(h)
       self._h = None
 
   @property

@@ -113,8 +113,9 @@ class _TableResource:
 
   def __del__(self):
     h = getattr(self, "h", None)
-    if h:
-      _lib.lib.mono_table_destroy(h)
+    lib = getattr(_lib, "lib", None) if _lib is not None else None  # None at interpreter exit
+    if h and lib is not None:
+      lib.mono_table_destroy(h)
       self.h = None
 
 

@@ -88,6 +88,43 @@ def test_random_stream_bit_exact(name, dedup):
   assert o.max_update_ts() == h.max_update_ts()
 
 
+@pytest.mark.parametrize("name", ["adagrad16", "ftrl6", "multi3", "adagrad64"])
+def test_hot_keys_chunked_sum(name):
+  """Keys with more than 4096 occurrences in a batch: the HIP path sums them in chunks (the one
+  documented change of summation order), so those rows are compared at 1e-6 of the gradient mass;
+  every other row - including a key with exactly 4096 occurrences and the sequential
+  (dedup off) mode at any length - stays bit-exact."""
+  cfg = CFGS[name]
+  o, h, _, _ = _pair(cfg)
+  rng = np.random.Generator(np.random.PCG64(11))
+  D, nseg = o.dim, len(cfg["segments"])
+  n = 30000
+  ids = (rng.integers(0, 5000, n) * 2654435761 + 3).astype(np.int64)
+  pos = rng.permutation(n)
+  hot, edge = np.int64(77), np.int64(78)
+  ids[pos[:9001]] = hot
+  ids[pos[9001:9001 + 4096]] = edge
+  lrs = np.full(nseg, 0.05, np.float32)
+  for step, dedup in enumerate([True, False, True]):
+    g = rng.normal(0, 0.1, (n, D)).astype(np.float32)
+    for t in (o, h):
+      t.apply_gradients(ids, g, lrs, req_time=10 + step, enable_dedup=dedup)
+    v = rng.normal(0, 1, (n, D)).astype(np.float32)
+    for t in (o, h):
+      t.assign_add(ids, v, req_time=20 + step)
+    oi, orows, ots = o.export()
+    hi, hrows, hts = h.export()
+    assert np.array_equal(oi, hi) and np.array_equal(ots, hts)
+    cold = oi != hot
+    assert np.array_equal(orows[cold].view(np.uint32), hrows[cold].view(np.uint32))
+    # weights of the hot row: |error| <= 1e-6 * sum |addends|
+    mass = np.abs(v[ids == hot]).sum(0).max() + 1.0
+    assert np.abs(orows[~cold][:, :D] - hrows[~cold][:, :D]).max() <= 1e-6 * mass
+    np.testing.assert_allclose(hrows[~cold], orows[~cold], rtol=1e-4, atol=1e-6 * mass)
+    # re-sync the hot row so later steps compare like with like
+    o.import_rows(oi[~cold], hrows[~cold], hts[~cold])
+
+
 def test_empty_and_ragged_inputs():
   o, h, _, _ = _pair(CFGS["adagrad16"])
   e = np.zeros(0, np.int64)
