@@ -670,6 +670,9 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
   const int r0 = loader ? lt / D : 0, c0 = loader ? lt - r0 * D : 0;
   const int dr = kLoaders / D, dc = kLoaders - dr * D;
   const uint32_t nq = *a.qcount;
+  // The consumer wave is a lone dependent chain; when this kernel shares CUs with k_apply its
+  // issue slots must not be arbitrated away, so it runs at raised wave priority.
+  if (!loader) __builtin_amdgcn_s_setprio(3);
   for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
     const LongSeg ls = a.queue[qi];
     float* row = t.rows + (uint64_t)ls.slot * R;

@@ -1,0 +1,268 @@
+"""Routing, exchange and pooling ops of the sparse-embedding path — the surface of the reference's
+monolith/native_training/distribution_ops.py, executed by libmonolith_hip.so on the current HIP
+stream. torch tensors are only buffer carriers; every kernel is reached through the C ABI
+(include/monolith_hip.h). There is no CPU fallback: CPU tensors are rejected.
+
+Differentiable ops are torch.autograd.Functions whose backward is the reference's registered
+gradient op (the @tf.RegisterGradient functions of distribution_ops.py).
+"""
+import ctypes as C
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+
+from monolith_amd import _lib
+from monolith_amd._lib import vp
+
+
+def _dev(t: torch.Tensor, who: str):
+  if not t.is_cuda:
+    raise _lib.MonolithHipError("%s: tensors must live on the GPU (no CPU fallback)" % who)
+  return t.device
+
+
+def _ptrs(tensors: Sequence[torch.Tensor]):
+  arr = (C.c_void_p * max(1, len(tensors)))()
+  for i, t in enumerate(tensors):
+    arr[i] = t.data_ptr()
+  return arr
+
+
+def _i32s(xs):
+  return (C.c_int32 * max(1, len(xs)))(*[int(x) for x in xs])
+
+
+def _i64s(xs):
+  return (C.c_int64 * max(1, len(xs)))(*[int(x) for x in xs])
+
+
+def _row_ids(id_indices: torch.Tensor) -> torch.Tensor:
+  """The reference passes `[n, 1]` (or `[n, k]`) index matrices whose column 0 is the output row
+  (reduce_op.cc:37-47); a plain `[n]` vector is accepted as well."""
+  if id_indices.dim() == 2:
+    id_indices = id_indices[:, 0]
+  return id_indices.to(torch.int64).contiguous()
+
+
+def _batch(id_length) -> int:
+  if isinstance(id_length, torch.Tensor):
+    return int(id_length.reshape(-1)[0].item())
+  if isinstance(id_length, (list, tuple)):
+    return int(id_length[0])
+  return int(id_length)
+
+
+# ----------------------------------------------------------------------------- routing
+def fused_reorder_by_indices(inputs: List[torch.Tensor], num_of_shards: int,
+                             dim_sizes: List[int]):
+  """distribution_ops.py:223-272 -> ops/fused_reorder_by_indices.cc:36-112.
+
+  Per-slot dedup (first occurrence keeps its place), ids grouped shard-major / slot-minor,
+  and for every input id the float offset of its embedding inside the fused embedding buffer
+  the lookup of `output` will produce.
+
+  Returns (output int64[U], shard_sizes int32[N] (host), sharded_slot_sizes int32[N*M] (host),
+  fused_embedding_offsets: list of int32 device tensors shaped like the inputs)."""
+  assert len(inputs) == len(dim_sizes) and len(inputs) > 0
+  dev = _dev(inputs[0], "fused_reorder_by_indices")
+  M, N = len(inputs), int(num_of_shards)
+  rank0_empty_shard = os.environ.get("MONOLITH_SYNC_EMPTY_RANK0_PS_SHARD", "1") == "1"
+  shard_rule = 1 if (N > 4 and rank0_empty_shard) else 0
+  flat = [x.reshape(-1).to(torch.int64).contiguous() for x in inputs]
+  lens = [int(x.numel()) for x in flat]
+  total = sum(lens)
+  out_ids = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+  offsets = [torch.empty(max(n, 1), dtype=torch.int32, device=dev) for n in lens]
+  shard_sizes = (C.c_int32 * N)()
+  slot_sizes = (C.c_int32 * (N * M))()
+  n_unique = C.c_int64(0)
+  _lib.check(_lib.lib.mono_fused_reorder_by_indices(
+      _ptrs(flat), _i64s(lens), M, N, _i32s(dim_sizes), shard_rule, vp(out_ids),
+      C.byref(n_unique), shard_sizes, slot_sizes, _ptrs(offsets), _lib.stream_ptr(dev)))
+  return (out_ids[:n_unique.value],
+          torch.tensor(list(shard_sizes), dtype=torch.int32),
+          torch.tensor(list(slot_sizes), dtype=torch.int32),
+          [o[:n].reshape(x.shape) for o, n, x in zip(offsets, lens, inputs)])
+
+
+def fused_gather_embeddings_by_input_gradient(fused_embeddings, grads: List[torch.Tensor],
+                                              embedding_offsets: List[torch.Tensor],
+                                              embedding_dims: List[int]) -> torch.Tensor:
+  """distribution_ops.py:512-519 -> ops/map_id_to_embedding_op.cc:294-343. `fused_embeddings`
+  only supplies the output length (a tensor or an int). Accumulation order is the input order
+  (slot by slot, row by row), i.e. the reference's CPU kernel — deterministic."""
+  fused_len = int(fused_embeddings.numel()) if isinstance(fused_embeddings, torch.Tensor) \
+      else int(fused_embeddings)
+  dev = _dev(grads[0], "fused_gather_embeddings_by_input_gradient")
+  M = len(grads)
+  gs = [g.to(torch.float32).contiguous() for g in grads]
+  offs = [o.reshape(-1).to(torch.int32).contiguous() for o in embedding_offsets]
+  lens = [int(o.numel()) for o in offs]
+  out = torch.empty(max(fused_len, 1), dtype=torch.float32, device=dev)
+  _lib.check(_lib.lib.mono_fused_gather_embeddings_by_input_gradient(
+      C.c_int64(fused_len), _ptrs(gs), _ptrs(offs), _i64s(lens), _i32s(embedding_dims), M, vp(out),
+      _lib.stream_ptr(dev)))
+  return out[:fused_len]
+
+
+class _FusedGather(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, fused, dims, *offsets):
+    dev = _dev(fused, "fused_gather_embeddings_by_input")
+    fused_c = fused.to(torch.float32).contiguous()
+    offs = [o.reshape(-1).to(torch.int32).contiguous() for o in offsets]
+    lens = [int(o.numel()) for o in offs]
+    outs = [torch.empty((n, d), dtype=torch.float32, device=dev) for n, d in zip(lens, dims)]
+    _lib.check(_lib.lib.mono_fused_gather_embeddings_by_input(
+        vp(fused_c), C.c_int64(fused_c.numel()), _ptrs(offs), _i64s(lens), _i32s(dims), len(offs),
+        _ptrs(outs), _lib.stream_ptr(dev)))
+    ctx.dims = list(dims)
+    ctx.fused_len = int(fused_c.numel())
+    ctx.save_for_backward(*offs)
+    return tuple(outs)
+
+  @staticmethod
+  def backward(ctx, *grads):
+    offs = ctx.saved_tensors
+    g = fused_gather_embeddings_by_input_gradient(ctx.fused_len, list(grads), list(offs), ctx.dims)
+    return (g, None) + (None,) * len(offs)
+
+
+def fused_gather_embeddings_by_input(fused_embeddings: torch.Tensor,
+                                     fused_embedding_offsets: List[torch.Tensor],
+                                     embedding_dims: List[int]) -> List[torch.Tensor]:
+  """distribution_ops.py:505-509 -> ops/map_id_to_embedding_op.cc:239-292: slot m's output row i
+  is fused_embeddings[offset_m[i] : offset_m[i] + dim_m]."""
+  return list(_FusedGather.apply(fused_embeddings, list(embedding_dims), *fused_embedding_offsets))
+
+
+# ----------------------------------------------------------------------------- pooling
+def _reduce_call(fn, row_ids, values, batch):
+  dev = _dev(values, "reduce")
+  v = values.to(torch.float32).contiguous()
+  n, dim = v.shape
+  out = torch.empty((batch, dim), dtype=torch.float32, device=dev)
+  _lib.check(fn(vp(row_ids), vp(v), C.c_int64(n), C.c_int64(dim), C.c_int64(batch), vp(out),
+                _lib.stream_ptr(dev)))
+  return out
+
+
+def _reduce_grad_call(fn, row_ids, grads):
+  dev = _dev(grads, "reduce gradient")
+  g = grads.to(torch.float32).contiguous()
+  batch, dim = g.shape
+  n = int(row_ids.numel())
+  out = torch.empty((n, dim), dtype=torch.float32, device=dev)
+  _lib.check(fn(vp(row_ids), vp(g), C.c_int64(n), C.c_int64(dim), C.c_int64(batch), vp(out),
+                _lib.stream_ptr(dev)))
+  return out
+
+
+class _ReduceSum(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, row_ids, values, batch):
+    ctx.save_for_backward(row_ids)
+    return _reduce_call(_lib.lib.mono_reduce_sum, row_ids, values, batch)
+
+  @staticmethod
+  def backward(ctx, grad):  # distribution_ops.py:577-582
+    (row_ids,) = ctx.saved_tensors
+    return None, _reduce_grad_call(_lib.lib.mono_reduce_sum_gradient, row_ids, grad), None
+
+
+class _ReduceMean(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, row_ids, values, batch):
+    ctx.save_for_backward(row_ids)
+    return _reduce_call(_lib.lib.mono_reduce_mean, row_ids, values, batch)
+
+  @staticmethod
+  def backward(ctx, grad):  # distribution_ops.py:551-556
+    (row_ids,) = ctx.saved_tensors
+    return None, _reduce_grad_call(_lib.lib.mono_reduce_mean_gradient, row_ids, grad), None
+
+
+def reduce_sum(id_indices: torch.Tensor, id_values: torch.Tensor, id_length, name=None):
+  """distribution_ops.py:559-574 -> ops/reduce_op.cc:29-51: out[id_length, dim], row
+  id_indices[i, 0] accumulates id_values[i] in input order."""
+  return _ReduceSum.apply(_row_ids(id_indices), id_values, _batch(id_length))
+
+
+def reduce_mean(id_indices: torch.Tensor, id_values: torch.Tensor, id_length):
+  """distribution_ops.py:522-533 -> ops/reduce_op.cc:55-87 (empty rows stay zero)."""
+  return _ReduceMean.apply(_row_ids(id_indices), id_values, _batch(id_length))
+
+
+class _ReduceSumSplit(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, row_ids, values, batch, split_dims):
+    dev = _dev(values, "fused_reduce_sum_and_split")
+    v = values.to(torch.float32).contiguous()
+    n, dim = v.shape
+    outs = [torch.empty((batch, d), dtype=torch.float32, device=dev) for d in split_dims]
+    _lib.check(_lib.lib.mono_fused_reduce_sum_and_split(
+        vp(row_ids), vp(v), C.c_int64(n), C.c_int64(dim), C.c_int64(batch), _i32s(split_dims),
+        len(split_dims), _ptrs(outs), _lib.stream_ptr(dev)))
+    ctx.save_for_backward(row_ids)
+    ctx.split_dims = list(split_dims)
+    ctx.batch = batch
+    return tuple(outs)
+
+  @staticmethod
+  def backward(ctx, *grads):  # distribution_ops.py:662-668
+    (row_ids,) = ctx.saved_tensors
+    dev = grads[0].device
+    gs = [g.to(torch.float32).contiguous() for g in grads]
+    n = int(row_ids.numel())
+    out = torch.empty((n, sum(ctx.split_dims)), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib.mono_fused_reduce_sum_and_split_gradient(
+        vp(row_ids), _ptrs(gs), C.c_int64(n), C.c_int64(ctx.batch), _i32s(ctx.split_dims),
+        len(gs), vp(out), _lib.stream_ptr(dev)))
+    return None, out, None, None
+
+
+def fused_reduce_sum_and_split(id_indices: torch.Tensor, id_values: torch.Tensor, id_length,
+                               split_dims: List[int], name: str = None):
+  """distribution_ops.py:635-659 -> ops/reduce_op.cc:232-277: reduce_sum whose [batch, dim]
+  result is written directly as M tensors [batch, split_dims[m]]."""
+  return list(_ReduceSumSplit.apply(_row_ids(id_indices), id_values, _batch(id_length),
+                                    list(split_dims)))
+
+
+class _SegmentSum(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, n, out_rows, *tensors):
+    indices, values = tensors[:n], tensors[n:]
+    dev = _dev(values[0], "fused_sorted_segment_sum")
+    idx = [i.reshape(-1).to(torch.int32).contiguous() for i in indices]
+    vals = [v.to(torch.float32).contiguous() for v in values]
+    lens = [int(i.numel()) for i in idx]
+    dims = [int(v.shape[1]) for v in vals]
+    outs = [torch.empty((r, d), dtype=torch.float32, device=dev) for r, d in zip(out_rows, dims)]
+    _lib.check(_lib.lib.mono_fused_sorted_segment_sum(
+        _ptrs(idx), _ptrs(vals), _i64s(lens), _i64s(dims), _i64s(out_rows), n, _ptrs(outs),
+        _lib.stream_ptr(dev)))
+    ctx.save_for_backward(*idx)
+    ctx.n = n
+    return tuple(outs)
+
+  @staticmethod
+  def backward(ctx, *grads):  # distribution_ops.py:624-632: gather_nd(grad, indices)
+    idx = ctx.saved_tensors
+    gv = [g.index_select(0, i.to(torch.int64)) for g, i in zip(grads, idx)]
+    return (None, None) + (None,) * ctx.n + tuple(gv)
+
+
+def fused_sorted_segment_sum(indices: List[torch.Tensor], values: List[torch.Tensor],
+                             shapes: List[Sequence[int]]):
+  """distribution_ops.py:608-621 -> ops/reduce_op.cu.cc:53-161: N sorted segment sums in one
+  call; output i has shape `shapes[i]` = [rows_i, dim_i]."""
+  n = len(indices)
+  out_rows = [int(s[0]) for s in shapes]
+  return list(_SegmentSum.apply(n, out_rows, *indices, *values))
