@@ -1,0 +1,170 @@
+"""Sync-training embedding exchange — the surface of
+monolith/native_training/distributed_ps_sync.py:110-545 (DistributedMultiTypeHashTableMpi).
+
+One process per GPU. Rank r owns the rows of shard r (fused_reorder_by_indices' shard rule); a
+step is
+
+  lookup:           F1 reorder/dedup -> a2a(sizes int32[K]) + a2a-v(FIDs int64)
+                    -> fused multi-table lookup on the owner -> a2a-v(rows fp32)
+                    -> F2 gather by the offsets F1 produced
+  apply_gradients:  F2 gradient (in-order scatter-add) -> a2a-v(grads fp32, splits swapped)
+                    -> fused multi-table optimize on the owner
+
+The reference's Horovod / BytePS alltoall (distributed_ps_sync.py:170-193,230-283,369-496) is
+`torch.distributed.all_to_all_single` here: RCCL over xGMI on the GPUs (backend "nccl"), gloo in
+the CPU tests. Message sizes are exchanged explicitly (hvd.alltoall(shard_sizes)); the rows /
+grads exchanges need no size message because both sides can compute them (recv_emb_splits =
+reshape(sharded_slot_sizes, [N, K]) @ dims, :211-216).
+
+`ops` names the module providing fused_reorder_by_indices / fused_gather_embeddings_by_input /
+..._gradient; it defaults to the HIP ops. (The CPU tests inject the oracle there to cover the
+exchange logic with gloo; the product path never does.)"""
+import copy
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from monolith_amd import multi_type_hash_table
+
+
+def _world(group=None) -> Tuple[int, int]:
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_rank(group), dist.get_world_size(group)
+  return 0, 1
+
+
+def alltoall(tensor: torch.Tensor, splits, recv_splits=None, group=None):
+  """hvd.alltoall(tensor, splits[, recv_splits]) on dim 0. Returns (received, recv_splits).
+  `splits` / `recv_splits` are host int sequences (length world)."""
+  rank, world = _world(group)
+  splits = [int(x) for x in splits]
+  if world == 1:
+    return tensor, splits
+  if recv_splits is None:
+    # size message first: one int64 per peer
+    dev = tensor.device
+    s = torch.tensor(splits, dtype=torch.int64, device=dev)
+    r = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(r, s, group=group)
+    recv_splits = [int(x) for x in r.cpu().tolist()]
+  else:
+    recv_splits = [int(x) for x in recv_splits]
+  out = torch.empty((sum(recv_splits),) + tuple(tensor.shape[1:]), dtype=tensor.dtype,
+                    device=tensor.device)
+  dist.all_to_all_single(out, tensor.contiguous(), output_split_sizes=recv_splits,
+                         input_split_sizes=splits, group=group)
+  return out, recv_splits
+
+
+class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTable):
+  """distributed_ps_sync.py:110-545. table_factory(rank) builds this rank's local
+  (Merged)MultiTypeHashTable; it must offer fused_lookup / fused_apply_gradient /
+  get_table_dim_sizes."""
+
+  lookup_takes_bundle = True
+
+  def __init__(self, shard_num: int,
+               table_factory: Callable[[int], multi_type_hash_table.BaseMultiTypeHashTable],
+               queue_configs: Optional[Dict[str, int]] = None, group=None, ops=None):
+    self._shard_num = shard_num
+    self._group = group
+    rank, world = _world(group)
+    assert world == self._shard_num, "world size %d != shard_num %d" % (world, shard_num)
+    self._index = rank
+    self._table = table_factory(self._index)
+    self._output_dims = self._table.get_table_dim_sizes()
+    self._queue_configs = queue_configs or {}  # pipelining queues of the reference: not needed,
+    # the exchange is stream-ordered
+    if ops is None:
+      from monolith_amd import distribution_ops as ops  # HIP ops; raises without the library
+    self._ops = ops
+
+  def lookup(self, slot_to_id: Dict[str, torch.Tensor], auxiliary_bundle: Dict,
+             early_reorder_indicies_res_pack=None):
+    sorted_slot_keys = sorted(slot_to_id.keys())
+    slot_num = len(slot_to_id)
+    sorted_input = [slot_to_id[k] for k in sorted_slot_keys]
+    if early_reorder_indicies_res_pack:
+      all_fids, shard_sizes, sharded_slot_sizes, fused_embedding_offsets = \
+          early_reorder_indicies_res_pack
+    else:
+      all_fids, shard_sizes, sharded_slot_sizes, fused_embedding_offsets = \
+          self._ops.fused_reorder_by_indices(sorted_input, self._shard_num, self._output_dims)
+
+    # M: num_of_ids, N: num_of_shards, K: num_of_merged_tables, E: total embedding floats.
+    # id_flat_t: [M'], id_size_flat_t: [K*N] (source-shard major)
+    shard_sizes_h = [int(x) for x in torch.as_tensor(shard_sizes).tolist()]
+    id_flat_t, _ = alltoall(all_fids, shard_sizes_h, group=self._group)
+    sss = torch.as_tensor(sharded_slot_sizes, dtype=torch.int32)
+    sss_dev = sss.to(all_fids.device)
+    id_size_flat_t, _ = alltoall(sss_dev, [slot_num] * self._shard_num,
+                                 recv_splits=[slot_num] * self._shard_num, group=self._group)
+    auxiliary_bundle["shard_sizes"] = shard_sizes
+    auxiliary_bundle["fused_embedding_offsets"] = fused_embedding_offsets
+    auxiliary_bundle["id_flat_t"] = id_flat_t
+    auxiliary_bundle["id_size_flat_t"] = id_size_flat_t.cpu()
+
+    # fused_embeddings: [E], embedding_splits: [N], id_offsets / emb_offsets: [K*N]
+    fused_embeddings, embedding_splits, id_offsets, emb_offsets, _ = \
+        self._table.fused_lookup(id_flat_t, auxiliary_bundle["id_size_flat_t"], self._shard_num)
+    auxiliary_bundle["embedding_splits"] = embedding_splits
+    auxiliary_bundle["id_offsets"] = id_offsets
+    auxiliary_bundle["emb_offsets"] = emb_offsets
+    dims = torch.tensor(self._output_dims, dtype=torch.int32)
+    recv_emb_splits = (sss.reshape(self._shard_num, slot_num) * dims.unsqueeze(0)).sum(1)
+    auxiliary_bundle["recv_emb_splits"] = recv_emb_splits
+
+    # recv_embeddings: [E']
+    recv_embeddings, _ = alltoall(fused_embeddings, embedding_splits.tolist(),
+                                  recv_splits=recv_emb_splits.tolist(), group=self._group)
+    auxiliary_bundle["recv_embeddings_size"] = int(recv_embeddings.numel())
+
+    outputs = self._ops.fused_gather_embeddings_by_input(recv_embeddings, fused_embedding_offsets,
+                                                         self._output_dims)
+    slot_to_embedding = {k: outputs[i] for i, k in enumerate(sorted_slot_keys)}
+    return slot_to_embedding, auxiliary_bundle
+
+  def assign(self, slot_to_id_and_value):  # "assign is broken" in the reference (:317-321)
+    raise NotImplementedError
+
+  def assign_add(self, slot_to_id_and_value):  # (:323-327)
+    raise NotImplementedError
+
+  def apply_gradients(self, slot_to_id_and_grad: Dict[str, Tuple[torch.Tensor, torch.Tensor]],
+                      auxiliary_bundle: Dict, global_step, req_time=None):
+    """Fused update (distributed_ps_sync.py:330-521). Gradient rows of one FID coming from
+    different ranks stay separate entries of the owner's id list and are applied as separate
+    optimizer steps in source-shard-major order."""
+    if req_time is None:
+      req_time = 0
+    sorted_slot_keys = sorted(slot_to_id_and_grad.keys())
+    sorted_grads = [slot_to_id_and_grad[k][1] for k in sorted_slot_keys]
+
+    recv_embeddings_size = auxiliary_bundle.pop("recv_embeddings_size")
+    fused_embedding_offsets = auxiliary_bundle.pop("fused_embedding_offsets")
+    grad_flat = self._ops.fused_gather_embeddings_by_input_gradient(
+        recv_embeddings_size, sorted_grads, fused_embedding_offsets, self._output_dims)
+
+    recv_emb_splits = auxiliary_bundle.pop("recv_emb_splits")
+    embedding_splits = auxiliary_bundle.pop("embedding_splits")
+    grad_flat_t, _ = alltoall(grad_flat, recv_emb_splits.tolist(),
+                              recv_splits=embedding_splits.tolist(), group=self._group)
+    auxiliary_bundle.pop("shard_sizes")
+
+    updated_table = self._table.fused_apply_gradient(
+        auxiliary_bundle.pop("id_flat_t"), auxiliary_bundle.pop("id_size_flat_t"), grad_flat_t,
+        auxiliary_bundle.pop("id_offsets"), auxiliary_bundle.pop("emb_offsets"), global_step,
+        req_time, self._shard_num)
+    return self._copy_with_new_table(updated_table)
+
+  def as_op(self, name=None):
+    return self._table.as_op(name)
+
+  def get_table_dim_sizes(self) -> List[int]:
+    return self._table.get_table_dim_sizes()
+
+  def _copy_with_new_table(self, table):
+    copied = copy.copy(self)
+    copied._table = table
+    return copied
