@@ -5,8 +5,11 @@ occurrence + apply_gradients (dedup) of one gradient row per occurrence.
   python bench.py [--gpus N --steps K --warmup W]     (N > 1: launched by torch.distributed.run)
 
 metric value = (lookups + updates) / s = 2 * n * N / t_step, inputs resident in HBM.
-Multi-GPU: every rank owns an independent table + stream (weak scaling, no collective in the
-data path); the FID/embedding all-to-all path is measured by `--workload sharded`.
+Multi-GPU (N > 1): the 1e8-row table is sharded by floormod(fid, N) over the ranks; every rank
+draws its own batch of 65536 samples (weak scaling) and a step is the sync-training exchange of
+distributed_ps_sync: reorder/dedup -> all-to-all(FIDs) -> fused lookup on the owner ->
+all-to-all(rows) -> gather, then gather-gradient -> all-to-all(grads) -> fused optimize (RCCL).
+`--backend gloo` rehearses that path with several ranks on ONE GPU (not a measurement).
 """
 import argparse
 import ctypes as C
@@ -74,6 +77,121 @@ def cpu_baseline(ids_batches, grad, lr):
                     % (len(ids_np), len(ids_np[0]), t.size())}
 
 
+def main_sharded(args, rank, world, device):
+  """N > 1: DistributedMultiTypeHashTableMpi over one merged table sharded by floormod(fid, N)."""
+  import torch.distributed as dist
+  os.environ["MONOLITH_SYNC_EMPTY_RANK0_PS_SHARD"] = "0"  # plain mod-N: all ranks hold rows
+  from monolith_amd import distributed_ps_sync, entry, hash_table_ops, multi_type_hash_table
+  global SLOT_VOCAB
+  if args.rows != 1e8:
+    scale = args.rows / 1e8
+    SLOT_VOCAB = [max(10, int(v * scale)) for v in SLOT_VOCAB]
+  total_rows = sum(SLOT_VOCAB)
+  lr, D = 0.01, 16
+  tc = entry.EmbeddingHashTableConfig(
+      segments=[entry.CombineAsSegment(D, entry.RandomUniformInitializer(-0.05, 0.05),
+                                       entry.AdagradOptimizer(initial_accumulator_value=0.1))],
+      initial_capacity=int(total_rows / world * 1.05) + 1024, seed=1234)
+  cfgs = {"criteo": entry.HashTableConfigInstance(tc, [lr])}
+
+  def factory(idx):
+    return multi_type_hash_table.MultiTypeHashTable(
+        cfgs, lambda slot, c: hash_table_ops.hash_table_from_config(
+            c, name_suffix="bench_%s_%d" % (slot, idx)))
+
+  table = distributed_ps_sync.DistributedMultiTypeHashTableMpi(world, factory)
+  local = table._table._hash_tables["criteo"]
+  # populate this rank's shard: fid = slot << 48 | r with floormod(fid, N) == rank
+  chunk = 1 << 22
+  zeros = torch.zeros((chunk, D), dtype=torch.float32, device=device)
+  t0 = time.time()
+  for s_, v in enumerate(SLOT_VOCAB):
+    for lo in range(0, v, chunk):
+      m = min(chunk, v - lo)
+      ids = (torch.arange(lo, lo + m, device=device, dtype=torch.int64) | (s_ << 48))
+      ids = ids[torch.remainder(ids, world) == rank].contiguous()
+      if ids.numel():
+        local.assign_add(ids, zeros[:ids.numel()], req_time=1)
+  torch.cuda.synchronize()
+  t_pop = time.time() - t0
+  rows_live = torch.tensor([local.size()], dtype=torch.int64, device=device)
+  if args.backend == "gloo":
+    rows_live = rows_live.cpu()
+  if world > 1:
+    dist.all_reduce(rows_live)
+  assert int(rows_live.item()) == total_rows, (int(rows_live.item()), total_rows)
+
+  gen = torch.Generator(device=device)
+  gen.manual_seed(20250117 + rank)
+  n_pool = 8
+  pool = [make_batch(gen, args.batch, device, args.skew) for _ in range(n_pool)]
+  n = pool[0].numel()
+  grad = (torch.randn((n, D), generator=gen, device=device, dtype=torch.float32) * 0.1)
+  uniq = float(np.mean([torch.unique(b).numel() / n for b in pool]))
+
+  state = {"t": table}
+
+  def step(i):
+    ids = {"criteo": pool[i % n_pool]}
+    emb, bundle = state["t"].lookup(ids, auxiliary_bundle={})
+    state["t"] = state["t"].apply_gradients({"criteo": (ids["criteo"], grad)}, bundle,
+                                            global_step=i, req_time=10 + i)
+    return emb
+
+  def barrier():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+      torch.cuda.synchronize()
+
+  for i in range(args.warmup):
+    step(i)
+  barrier()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    step(args.warmup + i)
+  barrier()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([dt], dtype=torch.float64,
+                        device=device if args.backend == "nccl" else "cpu")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+  ms_per_step = dt / args.steps * 1e3
+
+  # per-GPU algorithmic HBM bytes of one step (SURVEY.md 8d): every occurrence is gathered and
+  # its gradient scattered on the requesting rank (2 * (4 + 4D) + 4D out + 4D grad), every
+  # per-rank-unique FID is looked up and updated once on its owner (144 + 72 + 268 B)
+  per_gpu_bytes = n * (8 + 4 * D * 2 + 8) + uniq * n * (144 + 72 + 268)
+  step_gbs = per_gpu_bytes / (ms_per_step * 1e-3) / 1e9
+  # xGMI: a per-rank-unique FID moves 8 B out, 4D B back, 4D B of gradient; (N-1)/N are remote
+  fabric_bytes = uniq * n * (8 + 8 * D) * (world - 1) / world
+  res = {
+      "metric": "FID lookups+updates/sec (node)", "value": 2.0 * n * world / (dt / args.steps),
+      "unit": "lookups+updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+      "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "config": {"workload": "criteo-shaped: 26 single-hot slots, %.3g-row table sharded by "
+                             "floormod(fid, %d), dim 16 fp32, batch %d per GPU, Adagrad, "
+                             "distributed_ps_sync lookup + apply_gradients (FID / row / grad "
+                             "all-to-all, backend %s)" % (total_rows, world, args.batch,
+                                                          args.backend),
+                 "fids_per_step_per_gpu": n, "unique_ratio_per_rank": uniq, "skew": args.skew,
+                 "parallelism": "table sharded over %d GPUs, all-to-all exchange" % world,
+                 "populate_s": t_pop, "table_rows": total_rows},
+      "roofline": {"bound": "hbm", "kernel": "whole step (per GPU)", "achieved": step_gbs,
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
+                   "traffic": None,
+                   "xgmi_GBps_per_gpu": fabric_bytes / (ms_per_step * 1e-3) / 1e9},
+      "cpu_baseline": None,
+  }
+  if rank == 0:
+    print(json.dumps(res))
+  if world > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -83,16 +201,27 @@ def main():
   ap.add_argument("--rows", type=float, default=1e8, help="debug: scale the table down")
   ap.add_argument("--skew", type=float, default=3.0, help="power-law exponent (1 = uniform)")
   ap.add_argument("--no-cpu", action="store_true")
+  ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (single-GPU rehearsal)")
+  ap.add_argument("--sharded", action="store_true",
+                  help="run the N > 1 exchange pipeline even at N = 1 (profiling aid)")
   args = ap.parse_args()
 
   rank = int(os.environ.get("RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if args.backend == "gloo":
+    local_rank = 0  # rehearsal: all ranks share the one GPU
   torch.cuda.set_device(local_rank)
   device = torch.device("cuda", local_rank)
   if world > 1:
     import torch.distributed as dist
-    dist.init_process_group("nccl", device_id=device)
+    if args.backend == "nccl":
+      dist.init_process_group("nccl", device_id=device)
+    else:
+      dist.init_process_group("gloo")
+    return main_sharded(args, rank, world, device)
+  if args.sharded:
+    return main_sharded(args, rank, world, device)
 
   from monolith_amd import _lib, entry, hash_table_ops
   global SLOT_VOCAB

@@ -76,6 +76,12 @@ struct Workspace {
   void release();
 };
 
+// table.hip: out[skeys[p] .. + D) += src[sidx[p]] over the sorted positions p, every segment summed
+// left to right (segments longer than 4096 in ordered chunks). `aligned4`: every key is a
+// multiple of 4 floats and `out` is 16-byte aligned (enables vector access).
+int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, const float* src,
+                     int D, bool aligned4, float* out, hipStream_t st);
+
 }  // namespace mono
 
 #endif  // MONO_COMMON_H_

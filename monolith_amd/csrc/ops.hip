@@ -234,25 +234,6 @@ __global__ void __launch_bounds__(256) k_gather_rows(const float* __restrict__ f
   }
 }
 
-// F2 backward: occurrences sharing an offset are summed in input order by the segment head.
-__global__ void __launch_bounds__(256) k_scatter_rows_sorted(const uint32_t* __restrict__ skey,
-                                                             const uint32_t* __restrict__ sidx,
-                                                             int64_t n, int dim,
-                                                             const float* __restrict__ g,
-                                                             float* __restrict__ out) {
-  const int64_t total = n * dim;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t j = e / dim;
-    const int k = (int)(e - j * dim);
-    const uint32_t key = skey[j];
-    if (j > 0 && skey[j - 1] == key) continue;
-    float acc = 0.f;
-    for (int64_t p = j; p < n && skey[p] == key; ++p) acc = g[(int64_t)sidx[p] * dim + k] + acc;
-    out[(int64_t)key + k] = acc;
-  }
-}
-
 // ------------------------------------------------------------------------------ F1 reorder
 struct ReorderArgs {
   int M, N, shard_rule;
@@ -312,7 +293,9 @@ __global__ void __launch_bounds__(256) k_reorder_insert(ReorderArgs a, const Slo
       cell = s.hash_base + (int64_t)p;
     }
     hcell[g] = (uint32_t)cell;
-    atomicMin(&hfirst[cell], (uint32_t)g);
+    // hfirst only decreases: an occurrence that already sees a smaller index has nothing to
+    // add, which spares the hot keys tens of thousands of serialised atomics on one word
+    if (__builtin_nontemporal_load(&hfirst[cell]) > (uint32_t)g) atomicMin(&hfirst[cell], (uint32_t)g);
   }
 }
 
@@ -338,15 +321,22 @@ __global__ void __launch_bounds__(256) k_reorder_keys(ReorderArgs a, const SlotM
 }
 
 __global__ void __launch_bounds__(256) k_reorder_dims(ReorderArgs a, const SlotMeta* sm,
-                                                      const uint32_t* skey, int32_t* dims,
-                                                      int32_t* hist) {
+                                                      const uint32_t* skey, int32_t* dims) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.total;
        r += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t key = skey[r];
-    const bool uniq = key < (uint32_t)(a.N * a.M);
-    dims[r] = uniq ? sm[key % a.M].dim : 0;
-    if (uniq) atomicAdd(&hist[key], 1);
+    dims[r] = key < (uint32_t)(a.N * a.M) ? sm[key % a.M].dim : 0;
   }
+}
+
+// sharded_slot_sizes[n * M + m] = number of sorted keys equal to n * M + m (binary search on
+// the sorted keys: no counter contention whatever the skew).
+__global__ void __launch_bounds__(256) k_reorder_hist(ReorderArgs a, const uint32_t* skey,
+                                                      int32_t* hist) {
+  const int cells = a.N * a.M;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += gridDim.x * blockDim.x)
+    hist[c] = (int32_t)(lower_bound_dev(skey, a.total, (int64_t)c + 1) -
+                        lower_bound_dev(skey, a.total, (int64_t)c));
 }
 
 __global__ void __launch_bounds__(256) k_reorder_emit(ReorderArgs a, const SlotMeta* sm,
@@ -529,6 +519,8 @@ int mono_fused_gather_embeddings_by_input_gradient(int64_t fused_len, const floa
                                                    int M, float* out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   MONO_HIP(hipMemsetAsync(out, 0, (size_t)fused_len * sizeof(float), st));
+  bool aligned4 = ((uintptr_t)out & 15) == 0;
+  for (int m = 0; m < M; ++m) aligned4 = aligned4 && (h_dims[m] % 4 == 0);
   for (int m = 0; m < M; ++m) {
     const int64_t n = h_lens[m];
     if (n == 0) continue;
@@ -542,9 +534,8 @@ int mono_fused_gather_embeddings_by_input_gradient(int64_t fused_len, const floa
                        offsets[m], n, kin, iin);
     MONO_TRY(sort_pairs_u32<uint32_t>(kin, kout, iin, iout, (size_t)n,
                                       bits_for_u((uint64_t)fused_len), st));
-    hipLaunchKernelGGL(k_scatter_rows_sorted, dim3(grid_for(n * h_dims[m], 256)), dim3(256), 0, st,
-                       kout, iout, n, h_dims[m], grads[m], out);
-    MONO_HIP(hipGetLastError());
+    // duplicates of one offset are summed in input order by the table's segment machinery
+    MONO_TRY(segment_add_rows(kout, iout, n, grads[m], h_dims[m], aligned4, out, st));
   }
   return 0;
 }
@@ -619,7 +610,8 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   MONO_HIP(hipGetLastError());
   MONO_TRY(sort_pairs_u32<uint32_t>(skey, skey2, sidx, sidx2, (size_t)total,
                                     bits_for_u((uint64_t)N * M), st));
-  hipLaunchKernelGGL(k_reorder_dims, grid, blk, 0, st, a, d_sm, skey2, dims, hist);
+  hipLaunchKernelGGL(k_reorder_dims, grid, blk, 0, st, a, d_sm, skey2, dims);
+  hipLaunchKernelGGL(k_reorder_hist, dim3(grid_for((int64_t)N * M, 256)), blk, 0, st, a, skey2, hist);
   MONO_HIP(hipGetLastError());
   MONO_TRY(exclusive_scan_i32(dims, scan, (size_t)total, st));
   hipLaunchKernelGGL(k_reorder_emit, grid, blk, 0, st, a, d_sm, skey2, sidx2, scan, hcell, hfirst,

@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
       }
     }
   }
-  if (sub == 0) t.ts[slot] = a.ts;
+  if (sub == 0 && t.ts) t.ts[slot] = a.ts;
 }
 
 // Segment classification (no-filter path): kClsItems sorted positions per thread. Segment heads
@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         }
       }
     }
-    if (tid == 0 && ls.part == kNoPart) t.ts[ls.slot] = a.ts;
+    if (tid == 0 && ls.part == kNoPart && t.ts) t.ts[ls.slot] = a.ts;
   }
 }
 
@@ -894,7 +894,7 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
         if (kind == MONO_OPT_FTRL) row[st1] = s1;
       }
     }
-    if (threadIdx.x == 0) t.ts[sp.slot] = a.ts;
+    if (threadIdx.x == 0 && t.ts) t.ts[sp.slot] = a.ts;
   }
 }
 
@@ -1168,6 +1168,36 @@ static int launch_apply(Table* t, ApplyArgs& a, uint2* heads, uint32_t* nheads, 
   return 0;
 }
 
+// Scratch behind the apply kernels: counters, long-segment queue, split-key queue, chunk sums,
+// compacted heads.
+struct QueueLayout {
+  size_t lq, cq, pt, heads;
+};
+static QueueLayout queue_layout(int64_t n, int dim) {
+  QueueLayout q;
+  const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
+  q.lq = (((size_t)n / kLongSeg + 2) * sizeof(LongSeg) + 255) & ~(size_t)255;
+  q.cq = (((size_t)n / kChunk + 2) * sizeof(SplitSeg) + 255) & ~(size_t)255;
+  q.pt = (((size_t)n / (kChunk / 2) + 2) * (size_t)dim * sizeof(float) + 255) & ~(size_t)255;
+  q.heads = n_al * sizeof(uint2);
+  return q;
+}
+static size_t queue_bytes(int64_t n, int dim) {
+  QueueLayout q = queue_layout(n, dim);
+  return 256 + q.lq + q.cq + q.pt + q.heads;
+}
+static int queue_setup(ApplyArgs* a, char* q_base, int64_t n, int dim, uint2** heads,
+                       hipStream_t st) {
+  QueueLayout q = queue_layout(n, dim);
+  a->qcount = (uint32_t*)q_base;
+  a->queue = (LongSeg*)(q_base + 256);
+  a->cqueue = (SplitSeg*)(q_base + 256 + q.lq);
+  a->partials = (float*)(q_base + 256 + q.lq + q.cq);
+  *heads = (uint2*)(q_base + 256 + q.lq + q.cq + q.pt);
+  MONO_HIP(hipMemsetAsync(a->qcount, 0, 4 * sizeof(uint32_t), st));
+  return 0;
+}
+
 static int bits_for(uint64_t max_value) {
   int b = 1;
   while (b < 64 && (max_value >> b) != 0) ++b;
@@ -1198,10 +1228,7 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
 
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
-  const size_t lq_bytes = (((size_t)n / kLongSeg + 2) * sizeof(LongSeg) + 255) & ~(size_t)255;
-  const size_t cq_bytes = (((size_t)n / kChunk + 2) * sizeof(SplitSeg) + 255) & ~(size_t)255;
-  const size_t pt_bytes = (((size_t)n / (kChunk / 2) + 2) * t->d.dim * sizeof(float) + 255) & ~(size_t)255;
-  const size_t q_bytes = 256 + lq_bytes + cq_bytes + pt_bytes + n_al * sizeof(uint2);
+  const size_t q_bytes = queue_bytes(n, t->d.dim);
   char* q_base = nullptr;
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[0], st));
   if (!from_keys) {
@@ -1245,17 +1272,48 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
     a.skeys = key_out;
     a.sidx = idx_out;
   }
-  a.qcount = (uint32_t*)q_base;
-  a.queue = (LongSeg*)(q_base + 256);
-  a.cqueue = (SplitSeg*)(q_base + 256 + lq_bytes);
-  a.partials = (float*)(q_base + 256 + lq_bytes + cq_bytes);
-  uint2* heads = (uint2*)(q_base + 256 + lq_bytes + cq_bytes + pt_bytes);
-  MONO_HIP(hipMemsetAsync(a.qcount, 0, 4 * sizeof(uint32_t), st));
+  uint2* heads = nullptr;
+  MONO_TRY(queue_setup(&a, q_base, n, t->d.dim, &heads, st));
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[2], st));
   MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st));
   MONO_HIP(hipGetLastError());
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
   if (from_keys) MONO_TRY(filter_after_batch(filter, st));
+  return 0;
+}
+
+// In-order segmented row sum for the stateless ops (F2 gradient): out[key .. key + D) +=
+// src[sidx[p]] for every sorted position p of the segment `key`, left to right. It is the
+// table's apply machinery (sub-group kernel + long-segment kernel + chunk combine) pointed at a
+// flat float buffer: "slot" = float offset, row stride 1, no optimizer state, no timestamps.
+int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, const float* src,
+                     int D, bool aligned4, float* out, hipStream_t st) {
+  static Table ctx;  // scratch + aux stream of the stateless ops (one host thread per GPU)
+  if (n == 0) return 0;
+  MONO_REQUIRE(D > 0 && D <= kTileFloats, "segment_add_rows: dim %d exceeds %d", D, kTileFloats);
+  Table* t = &ctx;
+  t->d = TableDev{};
+  t->d.rows = out;
+  t->d.dim = D;
+  t->d.row_floats = 1;
+  t->d.n_seg = 1;
+  t->d.seg[0].dim = D;
+  t->d.seg[0].opt_kind = MONO_OPT_SGD;
+  t->d.seg[0].st_off = D;
+  t->opt_tmpl = OPTK_SGD;
+  t->vec = 1;
+  if (aligned4) t->vec = D % 32 == 0 ? 4 : D % 16 == 0 ? 2 : 1;
+  ApplyArgs a{};
+  a.skeys = skeys;
+  a.sidx = sidx;
+  a.n = n;
+  a.src = src;
+  a.mode = MODE_ASSIGN_ADD;
+  MONO_TRY(t->ws.ensure(queue_bytes(n, D)));
+  uint2* heads = nullptr;
+  MONO_TRY(queue_setup(&a, (char*)t->ws.ptr, n, D, &heads, st));
+  MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st));
+  MONO_HIP(hipGetLastError());
   return 0;
 }
 
@@ -1539,6 +1597,11 @@ int mono_tables_fused_lookup(void* const* tables, int K, const int64_t* ids,
     prev = output_dim;
   }
   if (!out_emb) return 0;
+  if (K == 1) {  // one table: the shard-major cells are one contiguous id list
+    const int64_t total = (int64_t)h_id_offsets[cnt - 1] + h_fused_slot_size[cnt - 1];
+    if (total == 0) return 0;
+    return mono_table_lookup(tables[0], ids, total, out_emb, stream);
+  }
   for (int idx = 0; idx < cnt; ++idx) {
     if (h_fused_slot_size[idx] == 0) continue;
     MONO_TRY(mono_table_lookup(tables[idx % K], ids + h_id_offsets[idx], h_fused_slot_size[idx],
@@ -1558,6 +1621,34 @@ int mono_tables_fused_apply_gradient(void* const* tables, void* const* filters, 
   // ops/hash_table_update_op.cc:209-251; shard-major order is the canonical one
   std::vector<int> lr_off(K, 0);
   for (int k = 1; k < K; ++k) lr_off[k] = lr_off[k - 1] + h_lr_lengths[k - 1];
+  bool gated = false;  // a real (non-dummy) filter gates every cell against the table state it finds
+  if (filters && filters[0]) {
+    FilterDev fd{};
+    MONO_TRY(filter_dev_view(filters[0], &fd, (hipStream_t)stream));
+    gated = fd.kind != 0;
+  }
+  if (K == 1 && !enable_grad_accumulation && !gated) {
+    // One table, no per-cell accumulation: "every cell in shard-major order, every occurrence a
+    // separate step" is one sequential pass over the concatenated id list, provided the cells
+    // are laid out back to back (they are when the offsets come from mono_tables_fused_lookup).
+    Table* t0 = (Table*)tables[0];
+    const int64_t D = t0->d.dim;
+    bool contiguous = true;
+    int64_t total = 0;
+    for (int idx = 0; idx < N; ++idx) {
+      if (h_fused_slot_size[idx] > 0 &&
+          (h_id_offsets[idx] != total || (int64_t)h_grad_offsets[idx] != total * D))
+        contiguous = false;
+      total += h_fused_slot_size[idx];
+    }
+    if (contiguous) {
+      t0->max_update_ts = std::max(t0->max_update_ts, req_time);
+      if (total == 0) return 0;
+      return mono_table_apply_gradients(tables[0], filters ? filters[0] : nullptr, ids, grads,
+                                        total, h_learning_rates, h_lr_lengths[0], req_time,
+                                        global_step, 0, stream);
+    }
+  }
   for (int shard = 0; shard < N; ++shard)
     for (int k = 0; k < K; ++k) {
       int idx = shard * K + k;

@@ -41,6 +41,11 @@ def alltoall(tensor: torch.Tensor, splits, recv_splits=None, group=None):
   splits = [int(x) for x in splits]
   if world == 1:
     return tensor, splits
+  if tensor.is_cuda and dist.get_backend(group) == "gloo":
+    # gloo has no device all-to-all: stage through the host (single-GPU rehearsals only; the
+    # production backend is "nccl" = RCCL, which exchanges device buffers over xGMI directly)
+    out, recv_splits = alltoall(tensor.cpu(), splits, recv_splits, group)
+    return out.to(tensor.device), recv_splits
   if recv_splits is None:
     # size message first: one int64 per peer
     dev = tensor.device
