@@ -76,6 +76,13 @@ struct Workspace {
   void release();
 };
 
+// sort.hip: stable LSD radix sort of (uint32 key, uint32 value) pairs on key bits [0, end_bit).
+// vin == nullptr sorts the identity permutation (values = input positions). kin / vin are not
+// modified; `tmp` needs sort_pairs_tmp_bytes(n, end_bit) bytes of device scratch.
+size_t sort_pairs_tmp_bytes(size_t n, int end_bit);
+int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                   size_t n, int end_bit, void* tmp, size_t tmp_bytes, hipStream_t st);
+
 // table.hip: out[skeys[p] .. + D) += src[sidx[p]] over the sorted positions p, every segment summed
 // left to right (segments longer than 4096 in ordered chunks). `aligned4`: every key is a
 // multiple of 4 floats and `out` is 16-byte aligned (enables vector access).

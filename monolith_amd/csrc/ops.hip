@@ -30,14 +30,11 @@ static int bits_for_u(uint64_t max_value) {
   return b;
 }
 
-template <typename K>
-static int sort_pairs_u32(const K* kin, K* kout, const uint32_t* vin, uint32_t* vout, size_t n,
-                          int end_bit, hipStream_t st) {
-  size_t tmp = 0;
-  MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0, end_bit, st));
-  MONO_TRY(g_ws_sort.ensure(tmp + 256));
-  MONO_HIP(rocprim::radix_sort_pairs(g_ws_sort.ptr, tmp, kin, kout, vin, vout, n, 0, end_bit, st));
-  return 0;
+static int sort_pairs(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                      size_t n, int end_bit, hipStream_t st) {
+  const size_t tmp = sort_pairs_tmp_bytes(n, end_bit);
+  MONO_TRY(g_ws_sort.ensure(tmp));
+  return sort_pairs_u32(kin, kout, vin, vout, n, end_bit, g_ws_sort.ptr, tmp, st);
 }
 
 static int exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n, hipStream_t st) {
@@ -114,7 +111,7 @@ static int make_sorted_rows(const K* row_ids, int64_t n, int64_t batch, SortedRo
   uint32_t* iout = kout + n_al;
   hipLaunchKernelGGL(k_keys_to_u32<K>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, row_ids, n,
                      kin, iin);
-  MONO_TRY(sort_pairs_u32<uint32_t>(kin, kout, iin, iout, (size_t)n, bits_for_u((uint64_t)batch), st));
+  MONO_TRY(sort_pairs(kin, kout, iin, iout, (size_t)n, bits_for_u((uint64_t)batch), st));
   out->urows = kout;
   out->perm = iout;
   return 0;
@@ -532,7 +529,7 @@ int mono_fused_gather_embeddings_by_input_gradient(int64_t fused_len, const floa
     uint32_t* iout = kout + n_al;
     hipLaunchKernelGGL(k_keys_to_u32<int32_t>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st,
                        offsets[m], n, kin, iin);
-    MONO_TRY(sort_pairs_u32<uint32_t>(kin, kout, iin, iout, (size_t)n,
+    MONO_TRY(sort_pairs(kin, kout, iin, iout, (size_t)n,
                                       bits_for_u((uint64_t)fused_len), st));
     // duplicates of one offset are summed in input order by the table's segment machinery
     MONO_TRY(segment_add_rows(kout, iout, n, grads[m], h_dims[m], aligned4, out, st));
@@ -608,7 +605,7 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hkeys, hfirst, hcell);
   hipLaunchKernelGGL(k_reorder_keys, grid, blk, 0, st, a, d_sm, hfirst, hcell, skey, sidx);
   MONO_HIP(hipGetLastError());
-  MONO_TRY(sort_pairs_u32<uint32_t>(skey, skey2, sidx, sidx2, (size_t)total,
+  MONO_TRY(sort_pairs(skey, skey2, sidx, sidx2, (size_t)total,
                                     bits_for_u((uint64_t)N * M), st));
   hipLaunchKernelGGL(k_reorder_dims, grid, blk, 0, st, a, d_sm, skey2, dims);
   hipLaunchKernelGGL(k_reorder_hist, dim3(grid_for((int64_t)N * M, 256)), blk, 0, st, a, skey2, hist);

@@ -1,0 +1,237 @@
+// sort.hip — stable LSD radix sort of (uint32 key, uint32 value) pairs for gfx950.
+//
+// Every grouping step of the hot path (occurrences by table slot, by fused-embedding offset, by
+// shard * M + slot, by pooling row) is a stable sort of at most a few million 8-byte pairs on
+// 1..29 key bits. At that size a general-purpose library sort is launch-bound (buffer fills and
+// look-back state between passes); this one is three small kernels per 8-bit pass, no spinning:
+//
+//   k_sort_hist     per-tile digit histogram (LDS)
+//   k_sort_scan     per digit: running count over the preceding tiles, and the digit total
+//   k_sort_scatter  stable in-tile ranking with wave ballots, tile staged in digit order in LDS,
+//                   then every digit's run written as contiguous (coalesced) stores
+//
+// A tile is 8192 consecutive elements owned by one 512-thread workgroup; wave w owns elements
+// [1024 w, 1024 w + 1024) and walks them 64 at a time, so "rank among equal digits" is:
+// equal-digit lanes below me in this round (ballot match) + what my wave counted in earlier
+// rounds (LDS counter per wave and digit) + what lower waves counted (scan over waves). 8-bit
+// digits keep the runs a tile contributes to one digit at ~32 elements (128 B): with 10-bit
+// digits the scatter degenerates into 16-byte partial-line writes and runs 2x slower.
+#include <algorithm>
+
+#include "mono_common.h"
+
+namespace mono {
+
+constexpr int kSortThreads = 512;
+constexpr int kSortWaves = kSortThreads / 64;
+constexpr int kSortItems = 16;
+constexpr int kSortTile = kSortThreads * kSortItems;  // 8192 pairs = 64 KB of LDS staging
+constexpr int kSortMaxBits = 8;
+constexpr int kSortMaxDigits = 1 << kSortMaxBits;
+
+__global__ void __launch_bounds__(kSortThreads) k_sort_hist(const uint32_t* __restrict__ keys,
+                                                            int64_t n, int shift, int bits,
+                                                            uint32_t* __restrict__ tile_hist) {
+  __shared__ uint32_t h[kSortMaxDigits];
+  const int nd = 1 << bits;
+  for (int d = threadIdx.x; d < nd; d += kSortThreads) h[d] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t i = base + r * kSortThreads + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (uint32_t)(nd - 1)], 1u);
+  }
+  __syncthreads();
+  uint32_t* out = tile_hist + (size_t)blockIdx.x * nd;
+  for (int d = threadIdx.x; d < nd; d += kSortThreads) out[d] = h[d];
+}
+
+// One workgroup per 32 digits: 32 tile groups x 32 digits. In place: tile_hist[t][d] becomes the
+// number of elements with digit d in the tiles before t; dtot[d] = all elements with digit d.
+__global__ void __launch_bounds__(1024) k_sort_scan(uint32_t* __restrict__ tile_hist,
+                                                    uint32_t* __restrict__ dtot, int tiles,
+                                                    int bits) {
+  __shared__ uint32_t part[32][33];
+  const int nd = 1 << bits;
+  const int dl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int d = blockIdx.x * 32 + dl;
+  const int per = (tiles + 31) / 32;
+  const int t0 = min(tiles, g * per), t1 = min(tiles, t0 + per);
+  uint32_t sum = 0;
+  if (d < nd)
+    for (int t = t0; t < t1; ++t) sum += tile_hist[(size_t)t * nd + d];
+  part[g][dl] = sum;
+  __syncthreads();
+  if (d < nd) {
+    uint32_t run = 0;
+    for (int gg = 0; gg < g; ++gg) run += part[gg][dl];
+    for (int t = t0; t < t1; ++t) {
+      const uint32_t c = tile_hist[(size_t)t * nd + d];
+      tile_hist[(size_t)t * nd + d] = run;
+      run += c;
+    }
+    if (g == 31) dtot[d] = run;
+  }
+}
+
+// Exclusive scan of v[0 .. 256) by one wave (4 values per lane).
+__device__ __forceinline__ void wave_excl_scan_256(const uint32_t* in, uint32_t* out, int nd,
+                                                   int lane) {
+  uint32_t a[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = lane * 4 + k;
+    a[k] = d < nd ? in[d] : 0u;
+    s += a[k];
+  }
+  uint32_t inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  uint32_t run = inc - s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int d = lane * 4 + k;
+    if (d < nd) out[d] = run;
+    run += a[k];
+  }
+}
+
+__global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
+    const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, int64_t n, int shift,
+    int bits, const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ dtot,
+    uint32_t* __restrict__ kout, uint32_t* __restrict__ vout) {
+  __shared__ uint32_t cnt[kSortWaves][kSortMaxDigits];
+  __shared__ uint32_t ltot[kSortMaxDigits];   // elements of this tile per digit
+  __shared__ uint32_t lexc[kSortMaxDigits];   // ... exclusive scan = start of the digit's run
+  __shared__ uint32_t gpre[kSortMaxDigits];   // global start of the digit
+  __shared__ uint32_t sk[kSortTile], sv[kSortTile];
+  const int nd = 1 << bits;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < kSortWaves * kSortMaxDigits; i += kSortThreads)
+    (&cnt[0][0])[i] = 0;
+  __syncthreads();
+  const int64_t tile0 = (int64_t)blockIdx.x * kSortTile;
+  const int64_t base = tile0 + (int64_t)w * (64 * kSortItems);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    const bool valid = i < n;
+    key[r] = valid ? kin[i] : 0u;
+    val[r] = valid ? (vin ? vin[i] : (uint32_t)i) : 0u;
+  }
+  // stable rank inside the wave's 1024-element span
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const bool valid = base + r * 64 + lane < n;
+    const uint32_t d = (key[r] >> shift) & (uint32_t)(nd - 1);
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    if (valid) {
+      const uint32_t prev = cnt[w][d];  // all peers read the word before the leader updates it
+      rank[r] = prev + (uint32_t)__popcll(peers & lt);
+      if ((peers & lt) == 0) cnt[w][d] = prev + (uint32_t)__popcll(peers);
+    }
+  }
+  __syncthreads();
+  // per digit: start of every wave's share inside the digit's run, and the tile total
+  for (int d = threadIdx.x; d < nd; d += kSortThreads) {
+    uint32_t run = 0;
+#pragma unroll
+    for (int ww = 0; ww < kSortWaves; ++ww) {
+      const uint32_t c = cnt[ww][d];
+      cnt[ww][d] = run;
+      run += c;
+    }
+    ltot[d] = run;
+  }
+  __syncthreads();
+  if (w == 0) wave_excl_scan_256(ltot, lexc, nd, lane);
+  if (w == 1) wave_excl_scan_256(dtot, gpre, nd, lane);
+  __syncthreads();
+  // stage the tile in digit order
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    if (base + r * 64 + lane < n) {
+      const uint32_t d = (key[r] >> shift) & (uint32_t)(nd - 1);
+      const uint32_t lp = lexc[d] + cnt[w][d] + rank[r];
+      sk[lp] = key[r];
+      sv[lp] = val[r];
+    }
+  }
+  __syncthreads();
+  // runs of equal digits go out as contiguous, coalesced stores
+  const uint32_t* off = tile_off + (size_t)blockIdx.x * nd;
+  const int count = (int)min((int64_t)kSortTile, n - tile0);
+  for (int j = threadIdx.x; j < count; j += kSortThreads) {
+    const uint32_t k = sk[j];
+    const uint32_t d = (k >> shift) & (uint32_t)(nd - 1);
+    const uint32_t pos = gpre[d] + off[d] + ((uint32_t)j - lexc[d]);
+    kout[pos] = k;
+    vout[pos] = sv[j];
+  }
+}
+
+size_t sort_pairs_tmp_bytes(size_t n, int end_bit) {
+  const size_t n_al = (n + 63) & ~(size_t)63;
+  const size_t tiles = (n + kSortTile - 1) / kSortTile;
+  const int passes = (std::min(std::max(end_bit, 1), 32) + kSortMaxBits - 1) / kSortMaxBits;
+  size_t b = 256 + kSortMaxDigits * sizeof(uint32_t);                       // digit totals
+  b += ((tiles * kSortMaxDigits * sizeof(uint32_t)) + 255) & ~(size_t)255;  // tile histograms
+  if (passes > 1) b += 2 * n_al * sizeof(uint32_t);                         // ping-pong buffer
+  return b;
+}
+
+int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                   size_t n, int end_bit, void* tmp, size_t tmp_bytes, hipStream_t st) {
+  if (n == 0) return 0;
+  MONO_REQUIRE(n < 0xFFFFFFF0ull, "sort_pairs_u32: %zu elements exceed the 32-bit index range", n);
+  MONO_REQUIRE(tmp && tmp_bytes >= sort_pairs_tmp_bytes(n, end_bit),
+               "sort_pairs_u32: scratch too small");
+  if (end_bit < 1) end_bit = 1;
+  if (end_bit > 32) end_bit = 32;
+  const int passes = (end_bit + kSortMaxBits - 1) / kSortMaxBits;
+  const int tiles = (int)((n + kSortTile - 1) / kSortTile);
+  const size_t n_al = (n + 63) & ~(size_t)63;
+  char* p = (char*)tmp;
+  uint32_t* dtot = (uint32_t*)p;
+  p += 256 + kSortMaxDigits * sizeof(uint32_t);
+  uint32_t* thist = (uint32_t*)p;
+  p += (((size_t)tiles * kSortMaxDigits * sizeof(uint32_t)) + 255) & ~(size_t)255;
+  uint32_t* tk = (uint32_t*)p;
+  uint32_t* tv = tk + n_al;
+  // even split of the key bits over the passes (29 bits -> 8 + 7 + 7 + 7)
+  int shift = 0;
+  const uint32_t* src_k = kin;
+  const uint32_t* src_v = vin;
+  for (int ps = 0; ps < passes; ++ps) {
+    const int left = passes - ps;
+    const int bits = (end_bit - shift + left - 1) / left;
+    // the last pass must land in (kout, vout): passes alternate backwards from there
+    const bool to_out = ((passes - 1 - ps) & 1) == 0;
+    uint32_t* dst_k = to_out ? kout : tk;
+    uint32_t* dst_v = to_out ? vout : tv;
+    hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(kSortThreads), 0, st, src_k, (int64_t)n,
+                       shift, bits, thist);
+    hipLaunchKernelGGL(k_sort_scan, dim3(((1 << bits) + 31) / 32), dim3(1024), 0, st, thist, dtot,
+                       tiles, bits);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(tiles), dim3(kSortThreads), 0, st, src_k, src_v,
+                       (int64_t)n, shift, bits, thist, dtot, dst_k, dst_v);
+    src_k = dst_k;
+    src_v = dst_v;
+    shift += bits;
+  }
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace mono

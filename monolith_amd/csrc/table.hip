@@ -1233,11 +1233,8 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[0], st));
   if (!from_keys) {
     // (slot, idx) pairs -> stable radix sort on the bits a slot can occupy
-    size_t tmp_bytes = 0;
     const int end_bit = bits_for(t->d.cap + 1);
-    MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0,
-                                       end_bit, st));
+    size_t tmp_bytes = sort_pairs_tmp_bytes((size_t)n, end_bit);
     tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
     MONO_TRY(t->ws.ensure(4 * n_al * sizeof(uint32_t) + tmp_bytes + q_bytes));
     uint32_t* slot_in = (uint32_t*)t->ws.ptr;
@@ -1250,8 +1247,8 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
                        slot_in, idx_in);
     MONO_HIP(hipGetLastError());
     if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
-    MONO_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, slot_in, slot_out, idx_in, idx_out,
-                                       (size_t)n, 0, end_bit, st));
+    MONO_TRY(sort_pairs_u32(slot_in, slot_out, idx_in, idx_out, (size_t)n, end_bit, tmp, tmp_bytes,
+                            st));
     a.skeys = slot_out;
     a.sidx = idx_out;
   } else {
