@@ -20,6 +20,7 @@
 // sub-group walks a key's occurrences in input order — which is also what makes duplicate
 // handling bit-exact with the reference's sequential loops (SURVEY.md §8a closed forms).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 #include <vector>
@@ -1159,11 +1160,21 @@ static int launch_apply(Table* t, ApplyArgs& a, uint2* heads, uint32_t* nheads, 
     MONO_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     MONO_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
   }
+  static const bool serial = getenv("MONO_SERIAL_APPLY") != nullptr;  // profiling aid
+  if (serial) {
+    launch_long_o(t, a, lgrid, st);
+    launch_short(t, a, st);
+    return 0;
+  }
+  // The long kernel goes first on the caller's stream so its few hundred workgroups (LDS-heavy,
+  // long-lived) are resident before the sub-group kernel's ~27k short workgroups flood the
+  // dispatcher from the auxiliary stream; the other order leaves the long kernel to run
+  // mostly after the short one has drained.
   MONO_HIP(hipEventRecord(t->ev_fork, st));
+  launch_long_o(t, a, lgrid, st);
   MONO_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
-  launch_long_o(t, a, lgrid, t->aux);
+  launch_short(t, a, t->aux);
   MONO_HIP(hipEventRecord(t->ev_join, t->aux));
-  launch_short(t, a, st);
   MONO_HIP(hipStreamWaitEvent(st, t->ev_join, 0));
   return 0;
 }
