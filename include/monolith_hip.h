@@ -195,6 +195,49 @@ int mono_fused_sorted_segment_sum(const int32_t* const* indices, const float* co
 int mono_first_n(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
                  int64_t batch, int64_t max_seq, float* out, void* stream);
 
+/* ---- layout fusion ---- */
+/* One SliceConfig of one layout (idl/matrix/proto/example.proto SliceConfig / OutConfig), flattened
+ * by the host exactly as MonolithEmbeddingToLayoutBase's constructor and the Layout classes do
+ * (ops/fused_embedding_to_layout.cc:67-334): layouts in sorted-name order, slices in config order. */
+enum { MONO_POOL_SUM = 0, MONO_POOL_MEAN = 1, MONO_POOL_FIRSTN = 2 };
+typedef struct mono_layout_slice {
+  int32_t feature_idx; /* index among the sorted feature names = index into nfl_offset */
+  int32_t start, dim;  /* embedding columns [start, start + dim) */
+  int32_t pooling;     /* MONO_POOL_* */
+  int32_t max_seq;     /* FIRSTN: max_sequence_length */
+  int32_t out_index;   /* which output tensor (sorted layouts; NONE layouts: one per slice) */
+  int32_t out_stride;  /* floats per sample in that tensor (PtrWrapper::offset) */
+  int32_t out_offset;  /* float offset of the slice inside a sample (GetSlice) */
+  int32_t addn;        /* 1: the layout is ADDN - its slices accumulate in order (:553-583) */
+  int32_t first;       /* 1: first slice of its layout (slice_conf_i == 0) */
+} mono_layout_slice;
+
+/* ops/fused_embedding_to_layout.cc:403-695 (MonolithEmbeddingToLayout / V2). h_emb_ptrs[i] is
+ * the i-th embedding buffer a fid_offset's high word indexes (V2: already cut per feature by
+ * fid_list_row_split, :438-476), row stride h_emb_dims[i], h_emb_floats[i] floats long.
+ * fid_offset / feature_offset are device arrays; nfl_offset (bit 31 = shared) is a host array.
+ * Outputs are zero-filled, then written. */
+int mono_embedding_to_layout(const mono_layout_slice* h_slices, int n_slices,
+                             const float* const* h_emb_ptrs, const int32_t* h_emb_dims,
+                             const int64_t* h_emb_floats, int n_bufs, const uint64_t* fid_offset,
+                             int64_t n_fids, const int32_t* feature_offset, int64_t n_features,
+                             const uint32_t* h_nfl_offset, int n_nfl, int32_t batch,
+                             float* const* h_outs, const int64_t* h_out_floats, int n_outs,
+                             void* stream);
+/* ops/fused_embedding_to_layout.cc:703-976 (MonolithEmbeddingToLayoutGrad / V2). h_emb_grads[i]
+ * (shaped like embedding buffer i) are zero-filled, then every (unique fid, slice) receives the
+ * layout gradients of all its uses, summed in the reference's order (layout, slice, sample, fid).
+ * mean_divides = 0 reproduces the reference (MEAN scatters the undivided gradient, :929-937).
+ * Copies feature_offset to the host (synchronises the stream). */
+int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slices,
+                                  float* const* h_emb_grads, const int32_t* h_emb_dims,
+                                  const int64_t* h_emb_floats, int n_bufs,
+                                  const uint64_t* fid_offset, int64_t n_fids,
+                                  const int32_t* feature_offset, int64_t n_features,
+                                  const uint32_t* h_nfl_offset, int n_nfl, int32_t batch,
+                                  const float* const* h_out_grads, const int64_t* h_out_floats,
+                                  int n_outs, int mean_divides, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,489 @@
+// layout.hip — fused embedding-to-layout (G1) and its gradient (G2) for MI355X (gfx950).
+//
+//   forward   ops/fused_embedding_to_layout.cc:403-695
+//   gradient  ops/fused_embedding_to_layout.cc:703-976
+//
+// Forward: one thread per output element (group, sample, column): it walks the sample's FID run
+// in order and, for an ADDN layout, the layout's slices in order — the reference's summation
+// order exactly, so the result is bit-identical and independent of scheduling. Consecutive
+// threads read consecutive columns of the same embedding row (coalesced row gathers); the FID
+// descriptor (8 B) is a broadcast within the row.
+//
+// Gradient: every use of an embedding slice (layout, slice, sample, fid) is a contribution to
+// one (unique fid, column range). Contributions are enumerated in the reference's order, keyed
+// by the float offset of their destination, stably sorted by key (sort.hip), and each segment is
+// summed left to right by one 8-lane sub-group — no float atomics, first touch = copy.
+#include <algorithm>
+#include <vector>
+
+#include "mono_common.h"
+
+namespace mono {
+
+static Workspace g_lws;       // descriptors + contribution arrays
+static Workspace g_lws_sort;  // sort scratch
+
+struct SliceDev {
+  int start, dim, pooling, max_seq;
+  int out_index, out_stride, out_offset, addn, first;
+  int shared, f0, feature_num;  // decoded nfl_offset entry of the slice's feature
+};
+struct GroupDev {  // a unit of forward work: one non-ADDN slice, or all slices of an ADDN layout
+  int s0, s1;
+  int width;  // floats per sample: dim, or max_seq * dim for FIRSTN
+  long long work_base;
+};
+struct BufDev {
+  float* ptr;
+  int dim;
+  long long floats;
+  long long gbase;  // offset of the buffer in the virtual concatenation of all buffers
+};
+
+struct LayoutArgs {
+  const SliceDev* slices;
+  const GroupDev* groups;
+  const BufDev* bufs;
+  float* const* outs;
+  int n_slices, n_groups, n_bufs;
+  const uint64_t* fid_offset;
+  long long n_fids;
+  const int32_t* feature_offset;
+  long long n_features;
+  int batch;
+  long long total_work;
+};
+
+__device__ __forceinline__ int fid_count_dev(const LayoutArgs& a, int f) {
+  return f < a.n_features - 1 ? a.feature_offset[f + 1] - a.feature_offset[f]
+                              : (int)a.n_fids - a.feature_offset[f];
+}
+
+// address of columns [start, start + dim) of the row a fid_offset names, or nullptr when the
+// descriptor points outside its buffer (corrupt input must not fault the GPU)
+__device__ __forceinline__ const float* slice_src(const LayoutArgs& a, uint64_t fo, int start,
+                                                  int dim) {
+  const uint32_t i1 = (uint32_t)(fo >> 32), i2 = (uint32_t)fo;
+  if (i1 >= (uint32_t)a.n_bufs) return nullptr;
+  const BufDev b = a.bufs[i1];
+  const long long off = (long long)i2 * b.dim + start;
+  if (off + dim > b.floats) return nullptr;
+  return b.ptr + off;
+}
+
+// pooled value of column `col` of slice `sc` for feature run f (SUM / MEAN, "copy first")
+__device__ __forceinline__ float pooled(const LayoutArgs& a, const SliceDev& sc, int f, int col,
+                                        int* fnum_out) {
+  const int fnum = fid_count_dev(a, f);
+  *fnum_out = fnum;
+  if (fnum == 0) return 0.f;
+  const int p0 = a.feature_offset[f];
+  float acc = 0.f;
+  for (int q = 0; q < fnum; ++q) {
+    const float* src = slice_src(a, a.fid_offset[p0 + q], sc.start, sc.dim);
+    const float v = src ? src[col] : 0.f;
+    acc = q == 0 ? v : v + acc;
+  }
+  if (sc.pooling == MONO_POOL_MEAN) acc = acc / fnum;
+  return acc;
+}
+
+__global__ void __launch_bounds__(256) k_layout_forward(LayoutArgs a) {
+  for (long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x; wi < a.total_work;
+       wi += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = a.n_groups - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (a.groups[mid].work_base <= wi) lo = mid; else hi = mid - 1;
+    }
+    const GroupDev g = a.groups[lo];
+    const long long local = wi - g.work_base;
+    const int b = (int)(local / g.width), k = (int)(local - (long long)b * g.width);
+    const SliceDev s0 = a.slices[g.s0];
+    float* out = a.outs[s0.out_index] + (long long)b * s0.out_stride + s0.out_offset;
+    if (s0.pooling == MONO_POOL_FIRSTN) {  // :657-662: out[seq * dim + col], zero padded
+      const int seq = k / s0.dim, col = k - seq * s0.dim;
+      const int f = s0.shared ? s0.f0 : s0.f0 + b;
+      if (seq < fid_count_dev(a, f)) {
+        const float* src = slice_src(a, a.fid_offset[a.feature_offset[f] + seq], s0.start, s0.dim);
+        if (src) out[k] = src[col];
+      }
+      continue;
+    }
+    if (!s0.addn) {
+      int fnum;
+      const float v = pooled(a, s0, s0.shared ? s0.f0 : s0.f0 + b, k, &fnum);
+      if (fnum) out[k] = v;
+      continue;
+    }
+    // ADDN (:553-598): the layout's slices accumulate into the zero-filled output in order
+    float cur = 0.f;
+    for (int si = g.s0; si < g.s1; ++si) {
+      const SliceDev sc = a.slices[si];
+      if (!sc.feature_num) continue;
+      int f = sc.shared ? sc.f0 : sc.f0 + b;
+      if (sc.pooling == MONO_POOL_MEAN || sc.shared) {  // pooled into a temporary first
+        // The reference's temporary lives across the samples of a slice and an empty run leaves
+        // it untouched (:553-583, GatherEmb returns early), so an empty run contributes the
+        // pooled value of the nearest earlier non-empty sample. Reproduced.
+        while (f > sc.f0 && fid_count_dev(a, f) == 0) --f;
+        int fnum;
+        const float t = pooled(a, sc, f, k, &fnum);
+        cur = sc.first ? t : t + cur;
+      } else {  // SUM: every fid is added straight into the output
+        const int fnum = fid_count_dev(a, f);
+        const int p0 = a.feature_offset[f];
+        for (int q = 0; q < fnum; ++q) {
+          const float* src = slice_src(a, a.fid_offset[p0 + q], sc.start, sc.dim);
+          cur = (src ? src[k] : 0.f) + cur;
+        }
+      }
+    }
+    out[k] = cur;
+  }
+}
+
+// ---------------------------------------------------------------------------------- gradient
+struct GradSliceDev {
+  long long cbase;  // first contribution index of the slice
+  int p0;           // first fid position of the slice's feature range
+  int len0;         // shared: length of the (single) run
+};
+
+struct GradArgs {
+  LayoutArgs l;
+  const GradSliceDev* gs;
+  const float* const* out_grads;
+  long long n_contrib;
+  uint32_t* key;
+  uint32_t* cslice;
+  const float** srcp;
+  uint32_t nokey;  // key of a use that scatters nothing (FIRSTN beyond max_seq); sorts last
+};
+
+__global__ void __launch_bounds__(256) k_layout_grad_enumerate(GradArgs a) {
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n_contrib;
+       c += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = a.l.n_slices - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (a.gs[mid].cbase <= c) lo = mid; else hi = mid - 1;
+    }
+    const SliceDev sc = a.l.slices[lo];
+    const GradSliceDev gs = a.gs[lo];
+    const long long local = c - gs.cbase;
+    int b, seq, p;
+    if (sc.shared) {  // every sample scatters to the one shared run (:874-876)
+      b = (int)(local / gs.len0);
+      seq = (int)(local - (long long)b * gs.len0);
+      p = gs.p0 + seq;
+    } else {
+      p = gs.p0 + (int)local;
+      // feature run holding fid position p: last f in [f0, f0 + batch) with feature_offset[f] <= p
+      int flo = sc.f0, fhi = sc.f0 + a.l.batch - 1;
+      while (flo < fhi) {
+        int mid = (flo + fhi + 1) >> 1;
+        if (a.l.feature_offset[mid] <= p) flo = mid; else fhi = mid - 1;
+      }
+      b = flo - sc.f0;
+      seq = p - a.l.feature_offset[flo];
+    }
+    uint32_t key = a.nokey;
+    const float* src = nullptr;
+    const uint64_t fo = a.l.fid_offset[p];
+    const uint32_t i1 = (uint32_t)(fo >> 32), i2 = (uint32_t)fo;
+    if (i1 < (uint32_t)a.l.n_bufs && !(sc.pooling == MONO_POOL_FIRSTN && seq >= sc.max_seq)) {
+      const BufDev bd = a.l.bufs[i1];
+      const long long off = (long long)i2 * bd.dim + sc.start;
+      if (off + sc.dim <= bd.floats) {
+        key = (uint32_t)(bd.gbase + off);
+        src = a.out_grads[sc.out_index] + (long long)b * sc.out_stride + sc.out_offset +
+              (sc.pooling == MONO_POOL_FIRSTN ? seq * sc.dim : 0);
+      }
+    }
+    a.key[c] = key;
+    a.cslice[c] = (uint32_t)lo;
+    a.srcp[c] = src;
+  }
+}
+
+// One 8-lane sub-group per sorted position; the head of a segment walks it in order
+// (first touch copies, later touches add: OptimizedSumpooling, :385-400).
+__global__ void __launch_bounds__(256) k_layout_grad_apply(GradArgs a, const uint32_t* skey,
+                                                           const uint32_t* sidx) {
+  const int sub = threadIdx.x & 7;
+  const long long j = (long long)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
+  if (j >= a.n_contrib) return;
+  const uint32_t key = skey[j];
+  if (key == a.nokey) return;
+  if (j > 0 && skey[j - 1] == key) return;
+  const int dim = a.l.slices[a.cslice[sidx[j]]].dim;
+  // destination: the buffer whose [gbase, gbase + floats) holds `key`
+  int lo = 0, hi = a.l.n_bufs - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (a.l.bufs[mid].gbase <= (long long)key) lo = mid; else hi = mid - 1;
+  }
+  float* dst = a.l.bufs[lo].ptr + ((long long)key - a.l.bufs[lo].gbase);
+  for (int k = sub; k < dim; k += 8) {
+    float acc = a.srcp[sidx[j]][k];
+    for (long long p = j + 1; p < a.n_contrib && skey[p] == key; ++p)
+      acc = a.srcp[sidx[p]][k] + acc;
+    dst[k] = acc;
+  }
+}
+
+static int bits_for_l(uint64_t max_value) {
+  int b = 1;
+  while (b < 64 && (max_value >> b) != 0) ++b;
+  return b;
+}
+
+struct HostPlan {
+  std::vector<SliceDev> slices;
+  std::vector<GroupDev> groups;
+  std::vector<BufDev> bufs;
+  long long total_work = 0;
+};
+
+static int build_plan(const mono_layout_slice* h_slices, int n_slices, float* const* emb_ptrs,
+                      const int32_t* h_emb_dims, const int64_t* h_emb_floats, int n_bufs,
+                      const uint32_t* h_nfl, int n_nfl, int64_t n_features, int32_t batch,
+                      int n_outs, const int64_t* h_out_floats, HostPlan* hp, const char* who) {
+  MONO_REQUIRE(h_slices && n_slices >= 0 && n_bufs >= 0 && batch >= 0 && n_nfl >= 0,
+               "%s: bad argument", who);
+  hp->slices.resize(n_slices);
+  for (int i = 0; i < n_slices; ++i) {
+    const mono_layout_slice& s = h_slices[i];
+    MONO_REQUIRE(s.feature_idx >= 0 && s.feature_idx < n_nfl, "%s: slice %d names feature %d of %d",
+                 who, i, s.feature_idx, n_nfl);
+    MONO_REQUIRE(s.dim > 0 && s.start >= 0 && s.out_index >= 0 && s.out_index < n_outs,
+                 "%s: slice %d is malformed", who, i);
+    MONO_REQUIRE(s.pooling >= MONO_POOL_SUM && s.pooling <= MONO_POOL_FIRSTN, "%s: pooling %d", who,
+                 s.pooling);
+    MONO_REQUIRE(!(s.addn && s.pooling == MONO_POOL_FIRSTN), "%s: ADDN over FIRSTN is unsupported",
+                 who);
+    const int width = s.pooling == MONO_POOL_FIRSTN ? s.max_seq * s.dim : s.dim;
+    MONO_REQUIRE(batch == 0 || (int64_t)(batch - 1) * s.out_stride + s.out_offset + width <=
+                                   h_out_floats[s.out_index],
+                 "%s: slice %d overruns output %d", who, i, s.out_index);
+    SliceDev& d = hp->slices[i];
+    d.start = s.start; d.dim = s.dim; d.pooling = s.pooling; d.max_seq = s.max_seq;
+    d.out_index = s.out_index; d.out_stride = s.out_stride; d.out_offset = s.out_offset;
+    d.addn = s.addn; d.first = s.first;
+    // GetFeatureInfo (:369-383)
+    const uint32_t e = h_nfl[s.feature_idx];
+    d.shared = (int)(e >> 31);
+    d.f0 = (int)(e & 0x7fffffffu);
+    d.feature_num = s.feature_idx < n_nfl - 1
+                        ? (int)(h_nfl[s.feature_idx + 1] & 0x7fffffffu) - d.f0
+                        : (int)n_features - d.f0;
+    MONO_REQUIRE(d.feature_num >= 0 && d.f0 + d.feature_num <= n_features,
+                 "%s: nfl_offset[%d] is outside feature_offset", who, s.feature_idx);
+    MONO_REQUIRE(d.feature_num == 0 || d.shared || d.feature_num >= batch,
+                 "%s: feature %d has %d runs for a batch of %d", who, s.feature_idx, d.feature_num,
+                 batch);
+  }
+  long long gb = 0;
+  hp->bufs.resize(n_bufs);
+  for (int i = 0; i < n_bufs; ++i) {
+    hp->bufs[i] = BufDev{emb_ptrs[i], h_emb_dims[i], (long long)h_emb_floats[i], gb};
+    gb += h_emb_floats[i];
+  }
+  // groups: an ADDN layout is one group, every other slice its own
+  long long work = 0;
+  for (int i = 0; i < n_slices;) {
+    int j = i + 1;
+    if (hp->slices[i].addn) {
+      while (j < n_slices && hp->slices[j].addn && !hp->slices[j].first) {
+        MONO_REQUIRE(hp->slices[j].dim == hp->slices[i].dim &&
+                         hp->slices[j].out_index == hp->slices[i].out_index,
+                     "%s: ADDN slices of one layout must agree in dim and output", who);
+        ++j;
+      }
+    }
+    const SliceDev& s = hp->slices[i];
+    bool live = false;
+    for (int k = i; k < j; ++k) live = live || hp->slices[k].feature_num > 0;
+    if (live) {
+      GroupDev g;
+      g.s0 = i; g.s1 = j;
+      g.width = s.pooling == MONO_POOL_FIRSTN ? s.max_seq * s.dim : s.dim;
+      g.work_base = work;
+      work += (long long)batch * g.width;
+      if (g.width > 0) hp->groups.push_back(g);
+    }
+    i = j;
+  }
+  hp->total_work = work;
+  return 0;
+}
+
+// uploads the plan; returns device pointers inside g_lws (256-byte aligned pieces)
+struct DevPlan {
+  SliceDev* slices;
+  GroupDev* groups;
+  BufDev* bufs;
+  float** outs;
+  char* rest;  // first free byte
+};
+
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static int upload_plan(const HostPlan& hp, const void* const* h_outs, int n_outs, size_t extra,
+                       DevPlan* dp, hipStream_t st) {
+  const size_t b_sl = al256(hp.slices.size() * sizeof(SliceDev) + 1);
+  const size_t b_gr = al256(hp.groups.size() * sizeof(GroupDev) + 1);
+  const size_t b_bf = al256(hp.bufs.size() * sizeof(BufDev) + 1);
+  const size_t b_ou = al256((size_t)n_outs * sizeof(void*) + 1);
+  MONO_TRY(g_lws.ensure(b_sl + b_gr + b_bf + b_ou + extra + 256));
+  char* p = (char*)g_lws.ptr;
+  dp->slices = (SliceDev*)p; p += b_sl;
+  dp->groups = (GroupDev*)p; p += b_gr;
+  dp->bufs = (BufDev*)p; p += b_bf;
+  dp->outs = (float**)p; p += b_ou;
+  dp->rest = p;
+  // pageable sources: hipMemcpyAsync stages them before returning, so the vectors may die
+  if (!hp.slices.empty())
+    MONO_HIP(hipMemcpyAsync(dp->slices, hp.slices.data(), hp.slices.size() * sizeof(SliceDev),
+                            hipMemcpyHostToDevice, st));
+  if (!hp.groups.empty())
+    MONO_HIP(hipMemcpyAsync(dp->groups, hp.groups.data(), hp.groups.size() * sizeof(GroupDev),
+                            hipMemcpyHostToDevice, st));
+  if (!hp.bufs.empty())
+    MONO_HIP(hipMemcpyAsync(dp->bufs, hp.bufs.data(), hp.bufs.size() * sizeof(BufDev),
+                            hipMemcpyHostToDevice, st));
+  if (n_outs > 0)
+    MONO_HIP(hipMemcpyAsync(dp->outs, h_outs, (size_t)n_outs * sizeof(void*), hipMemcpyHostToDevice,
+                            st));
+  return 0;
+}
+
+}  // namespace mono
+
+using namespace mono;
+
+extern "C" {
+
+int mono_embedding_to_layout(const mono_layout_slice* h_slices, int n_slices,
+                             const float* const* h_emb_ptrs, const int32_t* h_emb_dims,
+                             const int64_t* h_emb_floats, int n_bufs, const uint64_t* fid_offset,
+                             int64_t n_fids, const int32_t* feature_offset, int64_t n_features,
+                             const uint32_t* h_nfl_offset, int n_nfl, int32_t batch,
+                             float* const* h_outs, const int64_t* h_out_floats, int n_outs,
+                             void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  MONO_REQUIRE(n_fids < (int64_t)0x7FFFFFF0ll && n_features < (int64_t)0x7FFFFFF0ll,
+               "mono_embedding_to_layout: more than 2^31 fids / features");
+  HostPlan hp;
+  MONO_TRY(build_plan(h_slices, n_slices, const_cast<float* const*>(h_emb_ptrs), h_emb_dims,
+                      h_emb_floats, n_bufs, h_nfl_offset, n_nfl, n_features, batch, n_outs,
+                      h_out_floats, &hp, "mono_embedding_to_layout"));
+  for (int o = 0; o < n_outs; ++o)
+    if (h_out_floats[o] > 0)
+      MONO_HIP(hipMemsetAsync(h_outs[o], 0, (size_t)h_out_floats[o] * sizeof(float), st));
+  if (hp.total_work == 0) return 0;
+  DevPlan dp;
+  MONO_TRY(upload_plan(hp, (const void* const*)h_outs, n_outs, 0, &dp, st));
+  LayoutArgs a{};
+  a.slices = dp.slices; a.groups = dp.groups; a.bufs = dp.bufs; a.outs = dp.outs;
+  a.n_slices = n_slices; a.n_groups = (int)hp.groups.size(); a.n_bufs = n_bufs;
+  a.fid_offset = fid_offset; a.n_fids = n_fids;
+  a.feature_offset = feature_offset; a.n_features = n_features;
+  a.batch = batch; a.total_work = hp.total_work;
+  hipLaunchKernelGGL(k_layout_forward, dim3(grid_for(hp.total_work, 256)), dim3(256), 0, st, a);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slices,
+                                  float* const* h_emb_grads, const int32_t* h_emb_dims,
+                                  const int64_t* h_emb_floats, int n_bufs,
+                                  const uint64_t* fid_offset, int64_t n_fids,
+                                  const int32_t* feature_offset, int64_t n_features,
+                                  const uint32_t* h_nfl_offset, int n_nfl, int32_t batch,
+                                  const float* const* h_out_grads, const int64_t* h_out_floats,
+                                  int n_outs, int mean_divides, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  MONO_REQUIRE(n_fids < (int64_t)0x7FFFFFF0ll && n_features < (int64_t)0x7FFFFFF0ll,
+               "mono_embedding_to_layout_grad: more than 2^31 fids / features");
+  MONO_REQUIRE(!mean_divides, "mono_embedding_to_layout_grad: mean_divides is not implemented "
+                              "(the reference scatters the undivided gradient)");
+  HostPlan hp;
+  MONO_TRY(build_plan(h_slices, n_slices, h_emb_grads, h_emb_dims, h_emb_floats, n_bufs,
+                      h_nfl_offset, n_nfl, n_features, batch, n_outs, h_out_floats, &hp,
+                      "mono_embedding_to_layout_grad"));
+  long long total_floats = 0;
+  for (int i = 0; i < n_bufs; ++i) {
+    if (h_emb_floats[i] > 0)
+      MONO_HIP(hipMemsetAsync(h_emb_grads[i], 0, (size_t)h_emb_floats[i] * sizeof(float), st));
+    total_floats += h_emb_floats[i];
+  }
+  MONO_REQUIRE(total_floats < (long long)0xFFFFFFF0ll,
+               "mono_embedding_to_layout_grad: gradient buffers exceed 2^32 floats");
+  if (n_slices == 0 || batch == 0 || n_fids == 0) return 0;
+  // contribution ranges need feature_offset on the host
+  std::vector<int32_t> fo((size_t)n_features);
+  MONO_HIP(hipMemcpyAsync(fo.data(), feature_offset, (size_t)n_features * sizeof(int32_t),
+                          hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  auto run_end = [&](int f) -> long long {  // one past the last fid position of feature run f
+    return f < n_features - 1 ? fo[f + 1] : n_fids;
+  };
+  std::vector<GradSliceDev> gs(n_slices);
+  long long nc = 0;
+  for (int i = 0; i < n_slices; ++i) {
+    const SliceDev& s = hp.slices[i];
+    gs[i].cbase = nc;
+    gs[i].p0 = 0;
+    gs[i].len0 = 1;
+    if (!s.feature_num) continue;
+    gs[i].p0 = fo[s.f0];
+    if (s.shared) {
+      gs[i].len0 = (int)(run_end(s.f0) - fo[s.f0]);
+      nc += (long long)batch * gs[i].len0;
+      if (gs[i].len0 == 0) gs[i].len0 = 1;
+    } else {
+      nc += run_end(s.f0 + batch - 1) - fo[s.f0];
+    }
+  }
+  if (nc == 0) return 0;
+  MONO_REQUIRE(nc < (long long)0xFFFFFFF0ll, "mono_embedding_to_layout_grad: too many uses");
+  const size_t n_al = ((size_t)nc + 63) & ~(size_t)63;
+  const size_t b_gs = al256((size_t)n_slices * sizeof(GradSliceDev));
+  const size_t extra = b_gs + 4 * n_al * sizeof(uint32_t) + n_al * sizeof(void*) + 1024;
+  DevPlan dp;
+  MONO_TRY(upload_plan(hp, (const void* const*)h_out_grads, n_outs, extra, &dp, st));
+  char* p = dp.rest;
+  GradSliceDev* d_gs = (GradSliceDev*)p; p += b_gs;
+  const float** srcp = (const float**)p; p += al256(n_al * sizeof(void*));
+  uint32_t* key = (uint32_t*)p; p += n_al * sizeof(uint32_t);
+  uint32_t* cslice = (uint32_t*)p; p += n_al * sizeof(uint32_t);
+  uint32_t* skey = (uint32_t*)p; p += n_al * sizeof(uint32_t);
+  uint32_t* sidx = (uint32_t*)p;
+  MONO_HIP(hipMemcpyAsync(d_gs, gs.data(), (size_t)n_slices * sizeof(GradSliceDev),
+                          hipMemcpyHostToDevice, st));
+  GradArgs a{};
+  a.l.slices = dp.slices; a.l.groups = dp.groups; a.l.bufs = dp.bufs; a.l.outs = nullptr;
+  a.l.n_slices = n_slices; a.l.n_groups = (int)hp.groups.size(); a.l.n_bufs = n_bufs;
+  a.l.fid_offset = fid_offset; a.l.n_fids = n_fids;
+  a.l.feature_offset = feature_offset; a.l.n_features = n_features;
+  a.l.batch = batch;
+  a.gs = d_gs;
+  a.out_grads = (const float* const*)dp.outs;
+  a.n_contrib = nc;
+  a.key = key; a.cslice = cslice; a.srcp = srcp;
+  a.nokey = (uint32_t)total_floats;
+  hipLaunchKernelGGL(k_layout_grad_enumerate, dim3(grid_for(nc, 256)), dim3(256), 0, st, a);
+  MONO_HIP(hipGetLastError());
+  const int end_bit = bits_for_l((uint64_t)total_floats);  // nokey = total_floats sorts last
+  const size_t tmp = sort_pairs_tmp_bytes((size_t)nc, end_bit);
+  MONO_TRY(g_lws_sort.ensure(tmp));
+  MONO_TRY(sort_pairs_u32(key, skey, nullptr, sidx, (size_t)nc, end_bit, g_lws_sort.ptr, tmp, st));
+  hipLaunchKernelGGL(k_layout_grad_apply, dim3((unsigned)((nc + 31) / 32)), dim3(256), 0, st, a,
+                     skey, sidx);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -266,3 +266,102 @@ def fused_sorted_segment_sum(indices: List[torch.Tensor], values: List[torch.Ten
   n = len(indices)
   out_rows = [int(s[0]) for s in shapes]
   return list(_SegmentSum.apply(n, out_rows, *indices, *values))
+
+
+# ----------------------------------------------------------------------------- layout fusion
+def _layout_buffers(plan, embeddings_list, fid_list_row_split, ps_num, version):
+  """The embedding buffers a fid_offset's high word indexes: (tensor index, float offset, row
+  dim, floats). V1: the tensors themselves; V2: cut per feature (feature_configs.split_...)."""
+  from monolith_amd import feature_configs as fc
+  if version == 2:
+    return fc.split_embeddings_v2(plan, embeddings_list, fid_list_row_split, ps_num)
+  return [(i, 0, int(e.shape[1]), int(e.numel())) for i, e in enumerate(embeddings_list)]
+
+
+def _layout_call(plan, bufs, base_tensors, fid_offset, feature_offset, nfl_offset, batch, outs,
+                 grads_mode):
+  n_s = len(plan.slices)
+  slices = (type(plan.slices[0]) * max(1, n_s))(*plan.slices) if n_s else None
+  ptrs = (C.c_void_p * max(1, len(bufs)))(
+      *[base_tensors[t].data_ptr() + 4 * off for (t, off, _, _) in bufs])
+  dims = _i32s([d for (_, _, d, _) in bufs])
+  floats = _i64s([f for (_, _, _, f) in bufs])
+  nfl = torch.as_tensor(nfl_offset).cpu().to(torch.int64).tolist()
+  h_nfl = (C.c_uint32 * max(1, len(nfl)))(*[int(x) & 0xFFFFFFFF for x in nfl])
+  out_ptrs = _ptrs(outs)
+  out_floats = _i64s([int(o.numel()) for o in outs])
+  dev = fid_offset.device
+  args = [slices, n_s, ptrs, dims, floats, len(bufs), vp(fid_offset), C.c_int64(fid_offset.numel()),
+          vp(feature_offset), C.c_int64(feature_offset.numel()), h_nfl, len(nfl), C.c_int32(batch),
+          out_ptrs, out_floats, len(outs)]
+  if grads_mode:
+    _lib.check(_lib.lib.mono_embedding_to_layout_grad(*args, 0, _lib.stream_ptr(dev)))
+  else:
+    _lib.check(_lib.lib.mono_embedding_to_layout(*args, _lib.stream_ptr(dev)))
+
+
+def fused_embedding_to_layout_grad(nfl_offset, feature_offset, fid_offset, batch_size,
+                                   embeddings_list: List[torch.Tensor],
+                                   fid_list_row_split: List[torch.Tensor],
+                                   layout_tensors_grad: List[torch.Tensor], variant_type: str,
+                                   feature_cfgs, ps_num: int, parallel_flag=0,
+                                   version: int = 2) -> List[torch.Tensor]:
+  """distribution_ops.py:408-436 -> ops/fused_embedding_to_layout.cc:703-976: one gradient tensor
+  per embeddings_list entry. MEAN slices scatter the undivided gradient, as the reference does."""
+  from monolith_amd import feature_configs as fc
+  assert variant_type in {"example", "example_batch", "examplebatch", "instance"}
+  plan = fc.build_layout_plan(feature_cfgs)
+  dev = _dev(fid_offset, "fused_embedding_to_layout_grad")
+  bufs = _layout_buffers(plan, embeddings_list, fid_list_row_split, ps_num, version)
+  grads = [torch.zeros_like(e, dtype=torch.float32).contiguous() for e in embeddings_list]
+  gouts = [g.to(torch.float32).contiguous() for g in layout_tensors_grad]
+  _layout_call(plan, bufs, grads, fid_offset.contiguous(),
+               feature_offset.to(torch.int32).contiguous(), nfl_offset, _batch(batch_size), gouts,
+               True)
+  return grads
+
+
+class _EmbeddingToLayout(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, meta, fid_offset, feature_offset, *embeddings_list):
+    plan, fid_list_row_split, nfl_offset, batch, feature_cfgs, ps_num, version = meta
+    embs = [e.to(torch.float32).contiguous() for e in embeddings_list]
+    bufs = _layout_buffers(plan, embs, fid_list_row_split, ps_num, version)
+    dev = fid_offset.device
+    outs = [torch.empty([batch if d == -1 else d for d in shape], dtype=torch.float32, device=dev)
+            for shape in plan.out_shapes]
+    _layout_call(plan, bufs, embs, fid_offset, feature_offset, nfl_offset, batch, outs, False)
+    ctx.meta = meta
+    ctx.save_for_backward(fid_offset, feature_offset, *embs)
+    return tuple(outs)
+
+  @staticmethod
+  def backward(ctx, *grads):  # distribution_ops.py:360-405
+    plan, fid_list_row_split, nfl_offset, batch, feature_cfgs, ps_num, version = ctx.meta
+    fid_offset, feature_offset = ctx.saved_tensors[:2]
+    embs = list(ctx.saved_tensors[2:])
+    g = fused_embedding_to_layout_grad(nfl_offset, feature_offset, fid_offset, batch, embs,
+                                       fid_list_row_split, list(grads), "example_batch",
+                                       feature_cfgs, ps_num, version=version)
+    return (None, None, None) + tuple(g)
+
+
+def fused_embedding_to_layout(embeddings_list: List[torch.Tensor],
+                              fid_list_row_split: List[torch.Tensor], fid_offset: torch.Tensor,
+                              feature_offset: torch.Tensor, nfl_offset, batch_size,
+                              variant_type: str, feature_cfgs, ps_num: int, parallel_flag: int = 0,
+                              version: int = 2) -> List[torch.Tensor]:
+  """distribution_ops.py:313-357 -> ops/fused_embedding_to_layout.cc:403-695.
+
+  fid_offset: uint64 (index1 << 32 | row) as an int64 device tensor; feature_offset: int32 device
+  tensor; nfl_offset: uint32 values (bit 31 = shared feature), host side; fid_list_row_split:
+  host int64 tensors (V2). Returns one tensor per OutConfig shape, layouts in sorted-name order."""
+  from monolith_amd import feature_configs as fc
+  assert variant_type in {"example", "example_batch", "examplebatch", "instance"}
+  plan = fc.build_layout_plan(feature_cfgs)
+  _dev(fid_offset, "fused_embedding_to_layout")
+  meta = (plan, fid_list_row_split, nfl_offset, _batch(batch_size), feature_cfgs, ps_num, version)
+  return list(_EmbeddingToLayout.apply(meta, fid_offset.contiguous(),
+                                       feature_offset.to(torch.int32).contiguous(),
+                                       *embeddings_list))

@@ -380,3 +380,51 @@ def adagrad(num, norm, grad, lr, wd):
   lib().orc_adagrad(_p(num), _p(norm), _p(grad), C.c_int64(num.size), C.c_float(lr),
                     C.c_float(wd))
   return num, norm
+
+
+class OrcLayoutSlice(C.Structure):  # == mono_layout_slice
+  _fields_ = [("feature_idx", C.c_int32), ("start", C.c_int32), ("dim", C.c_int32),
+              ("pooling", C.c_int32), ("max_seq", C.c_int32), ("out_index", C.c_int32),
+              ("out_stride", C.c_int32), ("out_offset", C.c_int32), ("addn", C.c_int32),
+              ("first", C.c_int32)]
+
+
+def _layout_common(plan_slices, bufs, fid_offset, feature_offset, nfl_offset):
+  sl = (OrcLayoutSlice * max(1, len(plan_slices)))(*[
+      OrcLayoutSlice(s.feature_idx, s.start, s.dim, s.pooling, s.max_seq, s.out_index,
+                     s.out_stride, s.out_offset, s.addn, s.first) for s in plan_slices])
+  fo = np.ascontiguousarray(np.asarray(fid_offset).astype(np.uint64))
+  feat = np.ascontiguousarray(np.asarray(feature_offset, np.int32))
+  nfl = np.ascontiguousarray(np.asarray(nfl_offset).astype(np.uint32))
+  dims = np.ascontiguousarray(np.array([d for _, d in bufs], np.int32))
+  return sl, fo, feat, nfl, dims
+
+
+def embedding_to_layout(plan_slices, out_shapes, bufs, fid_offset, feature_offset, nfl_offset,
+                        batch):
+  """bufs: list of (float32 1-D array, row dim) in fid_offset buffer-index order."""
+  sl, fo, feat, nfl, dims = _layout_common(plan_slices, bufs, fid_offset, feature_offset, nfl_offset)
+  arrs = [_f32(a).reshape(-1) for a, _ in bufs]
+  outs = [np.empty([batch if d == -1 else d for d in shape], np.float32) for shape in out_shapes]
+  floats = np.array([o.size for o in outs], np.int64)
+  lib().orc_embedding_to_layout(sl, len(plan_slices), _ptr_array(arrs), _p(dims), len(arrs),
+                                _p(fo), C.c_int64(len(fo)), _p(feat), C.c_int64(len(feat)),
+                                _p(nfl), len(nfl), C.c_int32(batch), _ptr_array(outs), _p(floats),
+                                len(outs))
+  return outs
+
+
+def embedding_to_layout_grad(plan_slices, slice_idx_of, max_slice_num, bufs, fid_offset,
+                             feature_offset, nfl_offset, batch, out_grads, mean_divides=False):
+  """bufs: list of (floats, row dim); returns one flat gradient array per buffer."""
+  sl, fo, feat, nfl, dims = _layout_common(plan_slices, bufs, fid_offset, feature_offset, nfl_offset)
+  grads = [np.empty(int(n), np.float32) for n, _ in bufs]
+  floats = np.array([int(n) for n, _ in bufs], np.int64)
+  sidx = np.ascontiguousarray(np.asarray(slice_idx_of, np.int32))
+  og = [_f32(g).reshape(-1) for g in out_grads]
+  lib().orc_embedding_to_layout_grad(sl, _p(sidx), len(plan_slices), int(max_slice_num),
+                                     _ptr_array(grads), _p(dims), _p(floats), len(grads), _p(fo),
+                                     C.c_int64(len(fo)), _p(feat), C.c_int64(len(feat)), _p(nfl),
+                                     len(nfl), C.c_int32(batch), _ptr_array(og),
+                                     C.c_int(int(mean_divides)))
+  return grads

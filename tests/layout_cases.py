@@ -1,0 +1,189 @@
+"""Seeded inputs for the fused embedding-to-layout op, shaped like the reference's own test
+(fused_embedding_to_layout_test.py:175-330: several PS shards, tables of different widths, SUM /
+MEAN / FIRSTN features, shared features, ADDN / CONCAT / STACK / NONE layouts), plus the
+reference test's truth algorithm (:90-115 `pooling`, :435-481 assembly) restated in numpy.
+
+Unlike the reference test a fid that occurs in several samples maps to ONE embedding row, so the
+gradient really accumulates over uses."""
+import numpy as np
+
+from monolith_amd import feature_configs as fc
+
+
+def make_configs(n_slots=11, max_seq=3, split=(5, 8)):
+  cfgs = fc.FeatureConfigs()
+  bias, vec, ffm1, ffm2, first_n = (fc.OutConfig() for _ in range(5))
+  for slot in range(1, n_slots + 1):
+    name = "fc_slot_%d" % slot
+    if slot >= split[1]:
+      f = fc.FeatureConfig("table_one", [1, 4, 16], fc.PoolingType.FIRSTN, max_seq)
+      first_n.slice_configs.append(fc.SliceConfig(name, 1, 21))
+    else:
+      if slot < split[0]:
+        f = fc.FeatureConfig("table_one", [1, 4, 8], fc.PoolingType.SUM, 0)
+        ffm1.slice_configs.append(fc.SliceConfig(name, 5, 13))
+      else:
+        f = fc.FeatureConfig("table_two", [1, 4, 16], fc.PoolingType.MEAN, 0)
+        ffm2.slice_configs.append(fc.SliceConfig(name, 5, 21))
+      bias.slice_configs.append(fc.SliceConfig(name, 0, 1))
+      vec.slice_configs.append(fc.SliceConfig(name, 1, 5))
+    cfgs.feature_configs[name] = f
+  fc.infer_shape(bias, fc.OutType.ADDN)
+  fc.infer_shape(vec, fc.OutType.CONCAT)
+  fc.infer_shape(ffm1, fc.OutType.STACK)
+  fc.infer_shape(ffm2, fc.OutType.NONE)
+  fc.infer_shape(first_n, fc.OutType.NONE, max_seq)
+  cfgs.out_configs = {"bias": bias, "vec": vec, "ffm1": ffm1, "ffm2": ffm2, "firstN": first_n}
+  return cfgs
+
+
+def make_pooling_configs(n_slots=8, dim=16):
+  """Config-3 shaped: multi-hot slots, half SUM half MEAN, one CONCAT layout + one ADDN layout."""
+  cfgs = fc.FeatureConfigs()
+  concat, addn = fc.OutConfig(), fc.OutConfig()
+  for slot in range(n_slots):
+    name = "slot_%02d" % slot
+    pool = fc.PoolingType.SUM if slot % 2 == 0 else fc.PoolingType.MEAN
+    cfgs.feature_configs[name] = fc.FeatureConfig("t%d" % (slot % 2), [dim], pool, 0)
+    concat.slice_configs.append(fc.SliceConfig(name, 0, dim))
+    addn.slice_configs.append(fc.SliceConfig(name, 0, dim))
+  fc.infer_shape(concat, fc.OutType.CONCAT)
+  fc.infer_shape(addn, fc.OutType.ADDN)
+  cfgs.out_configs = {"concat": concat, "sum_all": addn}
+  return cfgs
+
+
+def make_inputs(cfgs, batch, ps_num, seed, max_fids=6, vocab=12, shared_every=2, empty_rate=0.1):
+  """Returns a dict with the V2 op inputs (numpy) and the bookkeeping the truth needs."""
+  rng = np.random.Generator(np.random.PCG64(seed))
+  fcs = cfgs.feature_configs
+  names = sorted(fcs)
+  tables = sorted({f.table for f in fcs.values()})
+  table_feats = {t: sorted(n for n in names if fcs[n].table == t) for t in tables}
+  pre_index, pre = {}, 0
+  for t in tables:
+    pre_index[t] = pre
+    pre += max(len(table_feats[t]), 1) * ps_num
+  # rows of every (feature, ps): fid -> row index, in first-use order
+  rows = {(n, p): {} for n in names for p in range(ps_num)}
+  fid_offset, feature_offset, nfl_offset = [], [], []
+  sample_fids = {}  # name -> list over samples of fid lists (shared: one list)
+  for i, name in enumerate(names):
+    f = fcs[name]
+    t = f.table
+    shared = shared_every > 0 and (i % shared_every == 1)
+    nfl_offset.append(len(feature_offset) | (int(shared) << 31))
+    runs = []
+    for b in range(1 if shared else batch):
+      k = 0 if rng.random() < empty_rate else int(rng.integers(1, max_fids + 1))
+      fids = [int(x) for x in (i + 1) * 100000 + rng.integers(0, vocab, k)]
+      if f.pooling_type != fc.PoolingType.FIRSTN:
+        fids = list(dict.fromkeys(fids))
+      runs.append(fids)
+      feature_offset.append(len(fid_offset))
+      for fid in fids:
+        ps = fid % ps_num
+        index1 = pre_index[t] + ps * len(table_feats[t]) + table_feats[t].index(name)
+        m = rows[(name, ps)]
+        index2 = m.setdefault(fid, len(m))
+        fid_offset.append((index1 << 32) | index2)
+    sample_fids[name] = (shared, runs)
+  # V2 buffers: embeddings_list[table_i * ps_num + ps] = rows of the table's features back to back
+  embeddings_list, row_split, fid_emb = [], [], {}
+  for t in tables:
+    for ps in range(ps_num):
+      parts, split = [], [0]
+      for n in table_feats[t]:
+        dim = sum(fcs[n].slice_dims)
+        m = rows[(n, ps)]
+        e = rng.normal(0, 1, (len(m), dim)).astype(np.float32)
+        for fid, r in m.items():
+          fid_emb[(n, fid)] = e[r]
+        parts.append(e.reshape(-1))
+        split.append(split[-1] + len(m))
+      embeddings_list.append(np.concatenate(parts) if parts else np.zeros(0, np.float32))
+      row_split.append(np.array(split, np.int64))
+  return {
+      "embeddings_list": embeddings_list, "fid_list_row_split": row_split,
+      "fid_offset": np.array(fid_offset, np.uint64), "feature_offset": np.array(feature_offset, np.int32),
+      "nfl_offset": np.array(nfl_offset, np.uint32), "batch": batch, "ps_num": ps_num,
+      "sample_fids": sample_fids, "fid_emb": fid_emb, "names": names,
+  }
+
+
+def pooling(pooling_type, in_data, max_length):
+  """fused_embedding_to_layout_test.py:90-115."""
+  data = in_data[0:max_length] if (max_length and len(in_data) > max_length) else in_data
+  if pooling_type == fc.PoolingType.SUM:
+    result = np.zeros_like(data[0])
+    for d in data:
+      result += d
+    return result
+  if pooling_type == fc.PoolingType.MEAN:
+    result = np.zeros_like(data[0])
+    for d in data:
+      result += d
+    result /= len(data)
+    return result
+  result = np.zeros((max_length, int(data[0].shape[-1])), np.float32)
+  for i, d in enumerate(data):
+    if i < max_length:
+      result[i, :] = d
+  return result
+
+
+def truth(cfgs, inp):
+  """One array per output tensor, layouts by sorted name (NONE layouts: one per slice)."""
+  fcs, batch = cfgs.feature_configs, inp["batch"]
+  outs = []
+  for lname in sorted(cfgs.out_configs):
+    oc = cfgs.out_configs[lname]
+    per_slice = []
+    for sc in oc.slice_configs:
+      f = fcs[sc.feature_name]
+      shared, runs = inp["sample_fids"][sc.feature_name]
+      dim = sc.end - sc.start
+      rows_out = []
+      for b in range(batch):
+        fids = runs[0] if shared else runs[b]
+        if fids:
+          data = [inp["fid_emb"][(sc.feature_name, fid)][sc.start:sc.end] for fid in fids]
+          rows_out.append(pooling(f.pooling_type, data, f.max_sequence_length))
+        elif f.pooling_type == fc.PoolingType.FIRSTN:
+          rows_out.append(np.zeros((f.max_sequence_length, dim), np.float32))
+        elif (oc.out_type == fc.OutType.ADDN and f.pooling_type == fc.PoolingType.MEAN and
+              rows_out):
+          # reference quirk (fused_embedding_to_layout.cc:553-583): the ADDN temporary lives
+          # across samples and GatherEmb leaves it untouched for an empty run, so the previous
+          # sample's pooled value is added again. The reference test never has empty runs.
+          rows_out.append(rows_out[-1].copy())
+        else:
+          rows_out.append(np.zeros(dim, np.float32))
+      per_slice.append(np.stack(rows_out))
+    if oc.out_type == fc.OutType.NONE:
+      outs.extend(per_slice)
+    elif oc.out_type == fc.OutType.CONCAT:
+      outs.append(np.concatenate(per_slice, axis=-1))
+    elif oc.out_type == fc.OutType.STACK:
+      outs.append(np.stack(per_slice, axis=1))
+    else:
+      acc = np.zeros_like(per_slice[0])
+      for p in per_slice:
+        acc = acc + p
+      outs.append(acc)
+  return outs
+
+
+def oracle_bufs(plan, inp):
+  """[(flat float32 array, row dim)] in fid_offset buffer-index order (the V2 cut, :438-476)."""
+  bufs = []
+  for table_i, dims in enumerate(plan.table_feature_dims):
+    for ps in range(inp["ps_num"]):
+      emb = inp["embeddings_list"][table_i * inp["ps_num"] + ps]
+      split = inp["fid_list_row_split"][table_i * inp["ps_num"] + ps]
+      pre = 0
+      for fi, dim in enumerate(dims):
+        cnt = int(split[fi + 1] - split[fi])
+        bufs.append((emb[pre:pre + cnt * dim], dim))
+        pre += cnt * dim
+  return bufs

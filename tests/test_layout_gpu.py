@@ -1,0 +1,85 @@
+"""GPU: fused_embedding_to_layout (+ gradient) through the C ABI vs the oracle, bit-exact, on the
+reference-test-shaped configuration (5 PS, 11 slots, ADDN / CONCAT / STACK / NONE / FIRSTN, shared
+features, empty runs) and on a config-3-shaped pooling workload."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu
+from tests import layout_cases as lc
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("ref_shaped", lc.make_configs, dict(batch=10, ps_num=5, seed=2)),
+         ("ref_shaped_b1", lc.make_configs, dict(batch=1, ps_num=2, seed=3)),
+         ("no_shared", lc.make_configs, dict(batch=64, ps_num=3, seed=4, shared_every=0)),
+         ("pooling", lc.make_pooling_configs, dict(batch=257, ps_num=4, seed=5, max_fids=80,
+                                                   vocab=300, shared_every=0)),
+         ("pooling_hot", lc.make_pooling_configs, dict(batch=512, ps_num=2, seed=6, max_fids=30,
+                                                       vocab=5, shared_every=3))]
+
+
+def dev():
+  return torch.device("cuda", 0)
+
+
+@pytest.mark.parametrize("name,mk,kw", CASES, ids=[c[0] for c in CASES])
+def test_layout_forward_and_gradient_bit_exact(name, mk, kw):
+  from monolith_amd import distribution_ops, feature_configs as fc
+  cfgs = mk()
+  inp = lc.make_inputs(cfgs, **kw)
+  plan = fc.build_layout_plan(cfgs)
+  embs = [torch.tensor(e, device=dev(), requires_grad=True) for e in inp["embeddings_list"]]
+  splits = [torch.tensor(s) for s in inp["fid_list_row_split"]]
+  fid_offset = torch.tensor(inp["fid_offset"].view(np.int64), device=dev())
+  feature_offset = torch.tensor(inp["feature_offset"], device=dev())
+  outs = distribution_ops.fused_embedding_to_layout(
+      embs, splits, fid_offset, feature_offset, inp["nfl_offset"], inp["batch"], "example_batch",
+      cfgs, inp["ps_num"])
+  bufs = lc.oracle_bufs(plan, inp)
+  exp = cpu.embedding_to_layout(plan.slices, plan.out_shapes, bufs, inp["fid_offset"],
+                                inp["feature_offset"], inp["nfl_offset"], inp["batch"])
+  assert len(outs) == len(exp)
+  for i, (o, e) in enumerate(zip(outs, exp)):
+    assert tuple(o.shape) == e.shape
+    assert np.array_equal(o.detach().cpu().numpy().view(np.uint32), e.view(np.uint32)), i
+
+  rng = np.random.Generator(np.random.PCG64(99))
+  gouts = [rng.normal(0, 1, e.shape).astype(np.float32) for e in exp]
+  torch.autograd.backward(outs, [torch.tensor(g, device=dev()) for g in gouts])
+  egrads = cpu.embedding_to_layout_grad(plan.slices, plan.slice_idx_of, plan.max_slice_num,
+                                        [(len(a), d) for a, d in bufs], inp["fid_offset"],
+                                        inp["feature_offset"], inp["nfl_offset"], inp["batch"],
+                                        gouts)
+  # the oracle's per-feature buffers are consecutive cuts of embeddings_list
+  cut = 0
+  for t, e in enumerate(embs):
+    got = e.grad.detach().cpu().numpy().reshape(-1)
+    pos = 0
+    while pos < got.size or (cut < len(bufs) and len(bufs[cut][0]) == 0 and pos == got.size):
+      n = len(bufs[cut][0])
+      assert np.array_equal(got[pos:pos + n].view(np.uint32), egrads[cut].view(np.uint32)), (t, cut)
+      pos += n
+      cut += 1
+      if cut >= len(bufs):
+        break
+  assert cut == len(bufs)
+
+
+def test_layout_v1_and_validation():
+  """Version 1 (embeddings_list = one [rows, dim] tensor per buffer) and argument checks."""
+  from monolith_amd import _lib, distribution_ops, feature_configs as fc
+  cfgs = fc.FeatureConfigs()
+  cfgs.feature_configs["a"] = fc.FeatureConfig("t", [2, 2], fc.PoolingType.SUM, 0)
+  oc = fc.OutConfig([fc.SliceConfig("a", 0, 2), fc.SliceConfig("a", 2, 4)])
+  fc.infer_shape(oc, fc.OutType.CONCAT)
+  cfgs.out_configs["o"] = oc
+  emb = torch.tensor([[1., 2., 3., 4.], [10., 20., 30., 40.]], device=dev())
+  fid_offset = torch.tensor([0, 1, 1], dtype=torch.int64, device=dev())
+  feature_offset = torch.tensor([0, 2], dtype=torch.int32, device=dev())
+  (out,) = distribution_ops.fused_embedding_to_layout([emb], [], fid_offset, feature_offset, [0], 2,
+                                                      "instance", cfgs, 1, version=1)
+  assert out.cpu().tolist() == [[11., 22., 33., 44.], [10., 20., 30., 40.]]
+  with pytest.raises(_lib.MonolithHipError):  # two runs for a batch of three
+    distribution_ops.fused_embedding_to_layout([emb], [], fid_offset, feature_offset, [0], 3,
+                                               "instance", cfgs, 1, version=1)
