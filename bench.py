@@ -317,6 +317,21 @@ def main():
   dom = max(("k_lookup", "k_find_or_claim", "k_apply"), key=lambda k: kern[k][0])
   achieved = kern[dom][1] / (kern[dom][0] * 1e-3) / 1e9
   step_gbs = (lookup_bytes + update_bytes) / (ms_per_step * 1e-3) / 1e9
+  # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE,
+  # separate rocprofv3 --pmc runs of this same command; calibration note in the summary file)
+  traffic, traffic_src = None, None
+  try:
+    with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+      pmc = json.load(f)["kernels"]
+    members = {"k_lookup": ["mono::k_lookup<4>"], "k_find_or_claim": ["mono::k_find_or_claim"],
+               "k_apply": ["mono::k_classify", "mono::k_apply<2, 1>", "mono::k_apply_long<1, 3>",
+                           "mono::k_combine<1>"]}[dom]
+    if args.batch == 65536 and args.rows == 1e8 and args.skew == 3.0:
+      traffic = sum((pmc[m]["FETCH_SIZE_KB_last_launch"] + pmc[m]["WRITE_SIZE_KB_last_launch"]) *
+                    1024.0 for m in members)
+      traffic_src = "profiles/r01_pmc_summary.json (" + " + ".join(members) + ")"
+  except (OSError, KeyError, ValueError):
+    pass
 
   res = {
       "metric": "FID lookups+updates/sec (node)", "value": 2.0 * n * world / (dt / args.steps),
@@ -330,7 +345,11 @@ def main():
                  "parallelism": "independent table per GPU" if world > 1 else "1 GPU",
                  "populate_s": t_pop, "table_rows": rows_live},
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                   "traffic_source": traffic_src, "algorithmic_bytes": kern[dom][1],
+                   "kernel_note": "k_apply = apply phase: k_classify, then k_apply (short "
+                                  "segments) beside k_apply_long (hot keys) + k_combine",
+                   "random_64B_line_ceiling_GBps": 3000.0,
                    "kernel_ms": {k: v[0] for k, v in kern.items()},
                    "step_algorithmic_GBps": step_gbs, "step_frac": step_gbs / HBM_PEAK_GBS},
   }

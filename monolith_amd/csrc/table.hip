@@ -103,6 +103,24 @@ __device__ inline uint32_t group_find(const TableDev& t, int64_t key, int sub, i
   return kNoSlot;
 }
 
+// group_find with the first bucket of the probe sequence already loaded (`k` = this lane's key
+// of bucket `b`): lets a sub-group keep the first-bucket reads of several ids in flight at once.
+__device__ inline uint32_t group_find_pre(const TableDev& t, int64_t key, uint64_t b, int64_t k,
+                                          int sub, int gshift) {
+  if (key == kEmpty || key == kTomb) {
+    int j = key == kTomb;
+    return t.special[j] ? (uint32_t)(t.cap + j) : kNoSlot;
+  }
+  for (uint64_t probes = 0; probes <= t.bucket_mask; ++probes) {
+    uint32_t m = group_bits(k == key, gshift);
+    if (m) return (uint32_t)(b * kBucket + (__ffs(m) - 1));
+    if (group_bits(k == kEmpty, gshift)) return kNoSlot;
+    b = (b + 1) & t.bucket_mask;
+    k = t.keys[b * kBucket + sub];
+  }
+  return kNoSlot;
+}
+
 // Find `key` or claim the first empty slot of its probe sequence. Slots only go EMPTY -> key
 // inside a launch, a possibly stale bucket image can only show EMPTY where a key already
 // sits, and every believed-EMPTY slot is confirmed by the CAS, so concurrent sub-groups
@@ -210,26 +228,45 @@ __device__ __forceinline__ void vstore(float* p, const float (&r)[V]) {
 // kernels
 
 // B1: ops/hash_table_lookup_op.cc:36-73 -> cuckoo_embedding_hash_table.cc:151-160.
+// A probe is two dependent random reads (key bucket, then row); with one id per sub-group at a
+// time the chip holds only ~4 MB of reads in flight, which at ~1.5 us of loaded HBM latency caps
+// the kernel near 2.7 TB/s (Little's law). Each sub-group therefore works on kIlp ids at once:
+// kIlp bucket reads are issued back to back, then kIlp row reads.
+constexpr int kIlp = 4;
 template <int V>
 __global__ void __launch_bounds__(256) k_lookup(TableDev t, const int64_t* __restrict__ ids,
                                                 int64_t n, float* __restrict__ out) {
   const int sub = lane_sub(), gshift = lane_gshift();
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
   const int D = t.dim;
-  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8; i < n; i += ngroups) {
-    int64_t key = ids[i];
-    uint32_t slot = group_find(t, key, sub, gshift);
-    float* dst = out + i * D;
-    const float* src = t.rows + (uint64_t)slot * t.row_floats;
-    for (int e = sub * V; e < D; e += 8 * V) {
-      float r[V];
-      if (slot != kNoSlot) {
-        vload<V>(r, src + e);
-      } else {
+  for (int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8) * kIlp; i0 < n;
+       i0 += ngroups * kIlp) {
+    int64_t key[kIlp], k0[kIlp];
+    uint64_t b[kIlp];
+    uint32_t slot[kIlp];
 #pragma unroll
-        for (int q = 0; q < V; ++q) r[q] = 0.f;
+    for (int q = 0; q < kIlp; ++q) key[q] = i0 + q < n ? ids[i0 + q] : kEmpty;
+#pragma unroll
+    for (int q = 0; q < kIlp; ++q) {
+      b[q] = mix64((uint64_t)key[q]) & t.bucket_mask;
+      k0[q] = t.keys[b[q] * kBucket + sub];
+    }
+#pragma unroll
+    for (int q = 0; q < kIlp; ++q) slot[q] = group_find_pre(t, key[q], b[q], k0[q], sub, gshift);
+    for (int e = sub * V; e < D; e += 8 * V) {
+      float r[kIlp][V];
+#pragma unroll
+      for (int q = 0; q < kIlp; ++q) {
+        if (slot[q] != kNoSlot) {
+          vload<V>(r[q], t.rows + (uint64_t)slot[q] * t.row_floats + e);
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; ++v) r[q][v] = 0.f;
+        }
       }
-      vstore<V>(dst + e, r);
+#pragma unroll
+      for (int q = 0; q < kIlp; ++q)
+        if (i0 + q < n) vstore<V>(out + (i0 + q) * D + e, r[q]);
     }
   }
 }
@@ -248,23 +285,49 @@ __global__ void __launch_bounds__(256) k_contains(TableDev t, const int64_t* __r
 // missing keys (cuckoo_embedding_hash_table.cc:284-291). Emits (slot, occurrence index) pairs.
 __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t* __restrict__ ids,
                                                        int64_t n, uint32_t* __restrict__ slot_out,
-                                                       uint32_t* __restrict__ idx_out) {
+                                                       uint32_t* __restrict__ idx_out,
+                                                       uint32_t* __restrict__ zero4) {
+  // the apply phase's four queue counters are cleared here: a separate memset costs ~10 us of
+  // stream bubble between the sort and k_classify
+  if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;
   const int sub = lane_sub(), gshift = lane_gshift();
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
-  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8; i < n; i += ngroups) {
-    int64_t key = ids[i];
-    bool claimed;
-    uint32_t slot = group_find_or_claim(t, key, sub, gshift, &claimed);
-    if (claimed) {
-      group_init_row(t, key, slot, sub);
-      if (sub == 0) {
-        t.ts[slot] = 0;
-        atomicAdd(&t.counters[0], 1ull);
-      }
+  for (int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8) * kIlp; i0 < n;
+       i0 += ngroups * kIlp) {
+    // first buckets of kIlp ids in flight together; the steady state (id present, first bucket)
+    // is decided from them, anything else takes the claiming probe
+    int64_t key[kIlp], k0[kIlp];
+    uint64_t b[kIlp];
+#pragma unroll
+    for (int q = 0; q < kIlp; ++q) key[q] = i0 + q < n ? ids[i0 + q] : kEmpty;
+#pragma unroll
+    for (int q = 0; q < kIlp; ++q) {
+      b[q] = mix64((uint64_t)key[q]) & t.bucket_mask;
+      k0[q] = t.keys[b[q] * kBucket + sub];
     }
-    if (sub == 0) {
-      slot_out[i] = slot;
-      idx_out[i] = (uint32_t)i;
+#pragma unroll
+    for (int q = 0; q < kIlp; ++q) {
+      if (i0 + q >= n) continue;
+      const bool special = key[q] == kEmpty || key[q] == kTomb;
+      uint32_t m = group_bits(!special && k0[q] == key[q], gshift);
+      uint32_t slot;
+      if (m) {
+        slot = (uint32_t)(b[q] * kBucket + (__ffs(m) - 1));
+      } else {
+        bool claimed;
+        slot = group_find_or_claim(t, key[q], sub, gshift, &claimed);
+        if (claimed) {
+          group_init_row(t, key[q], slot, sub);
+          if (sub == 0) {
+            t.ts[slot] = 0;
+            atomicAdd(&t.counters[0], 1ull);
+          }
+        }
+      }
+      if (sub == 0) {
+        slot_out[i0 + q] = slot;
+        idx_out[i0 + q] = (uint32_t)(i0 + q);
+      }
     }
   }
 }
@@ -292,7 +355,9 @@ struct ApplyArgs {
   uint32_t* qcount;          // [0] queue entries [1] compacted heads [2] split keys [3] partial rows
   struct SplitSeg* cqueue;   // keys whose segment was cut into chunks, finished by k_combine
   float* partials;           // [partial row][dim] chunk sums of the split keys
-  const uint2* heads;        // compacted (position, length) of the short segments, or nullptr
+  int chunk;                 // occurrences above which a key is split (kChunk)
+  const uint4* heads;        // compacted (position, length, slot, first index) of the short
+                             // segments, or nullptr
   const uint32_t* nheads;
 };
 
@@ -361,8 +426,8 @@ __device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, fl
 __device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t end, int64_t key,
                                     uint32_t slot, uint32_t fresh) {
   const int64_t len = end - first;
-  const bool split = a.mode != MODE_OPT_SEQ && len > kChunk;
-  const uint32_t nparts = split ? (uint32_t)((len + kChunk - 1) / kChunk) : 1u;
+  const bool split = a.mode != MODE_OPT_SEQ && len > a.chunk;
+  const uint32_t nparts = split ? (uint32_t)((len + a.chunk - 1) / a.chunk) : 1u;
   const int64_t csz = (len + nparts - 1) / nparts;
   const uint32_t q = atomicAdd(&a.qcount[0], nparts);
   uint32_t pbase = kNoPart;
@@ -393,7 +458,7 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
   int64_t j = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
   if (j >= a.n) return;
   const int D = t.dim, R = t.row_floats;
-  uint2 hd = make_uint2(0u, 0u);
+  uint4 hd = make_uint4(0u, 0u, 0u, 0u);
   if (a.heads) {  // compacted segment heads (k_classify): every sub-group has work
     if (j >= (int64_t)*a.nheads) return;
     hd = a.heads[j];
@@ -410,11 +475,13 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
     const uint32_t* sk = static_cast<const uint32_t*>(a.skeys);
     // four independent loads up front: the common single-occurrence segment then needs only
     // two dependent memory levels (sorted arrays -> row + gradient)
-    slot = sk[j];
-    idx0 = a.sidx[j];
-    if (a.heads) {
+    if (a.heads) {  // slot and first index ride in the head record: one memory level less
+      slot = hd.z;
+      idx0 = hd.w;
       end = j + hd.y;
     } else {
+      slot = sk[j];
+      idx0 = a.sidx[j];
       const uint32_t prev = j > 0 ? sk[j - 1] : ~slot;
       const uint32_t next = j + 1 < a.n ? sk[j + 1] : ~slot;
       if (prev == slot) return;
@@ -584,7 +651,9 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
       }
     }
   }
+#ifndef EXP_NO_TS
   if (sub == 0 && t.ts) t.ts[slot] = a.ts;
+#endif
 }
 
 // Segment classification (no-filter path): kClsItems sorted positions per thread. Segment heads
@@ -595,7 +664,7 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
 constexpr int kClsThreads = 1024;
 constexpr int kClsItems = 4;
 __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow_long,
-                                                          uint2* __restrict__ heads) {
+                                                          uint4* __restrict__ heads) {
   __shared__ uint32_t s_cnt, s_base;
   const uint32_t* __restrict__ sk = static_cast<const uint32_t*>(a.skeys);
   const int64_t n = a.n;
@@ -603,7 +672,7 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
   if (tid == 0) s_cnt = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * (kClsThreads * kClsItems);
-  uint32_t loc[kClsItems], len[kClsItems];
+  uint32_t loc[kClsItems], len[kClsItems], slotv[kClsItems], idxv[kClsItems];
   bool sh[kClsItems];
 #pragma unroll
   for (int k = 0; k < kClsItems; ++k) {
@@ -611,8 +680,11 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
     sh[k] = false;
     len[k] = 1;
     loc[k] = 0;
+    slotv[k] = idxv[k] = 0;
     if (j < n) {
       const uint32_t slot = sk[j];
+      slotv[k] = slot;
+      idxv[k] = a.sidx[j];
       const uint32_t prev = j > 0 ? sk[j - 1] : ~slot;
       const uint32_t next = j + 1 < n ? sk[j + 1] : ~slot;
       if (prev != slot && slot != kNoSlot) {
@@ -639,7 +711,8 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
 #pragma unroll
   for (int k = 0; k < kClsItems; ++k)
     if (sh[k])
-      heads[gb + loc[k]] = make_uint2((uint32_t)(base + (int64_t)k * kClsThreads + tid), len[k]);
+      heads[gb + loc[k]] = make_uint4((uint32_t)(base + (int64_t)k * kClsThreads + tid), len[k],
+                                      slotv[k], idxv[k]);
 }
 
 // Long segments: one 256-thread workgroup per key, split into roles. Waves 1-3 (192 loader
@@ -1076,7 +1149,7 @@ static int ensure_room(Table* t, int64_t incoming, hipStream_t st) {
 
 template <int V>
 static void launch_lookup(const Table* t, const int64_t* ids, int64_t n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(k_lookup<V>, dim3(grid_for(n, 32)), dim3(256), 0, st, t->d, ids, n, out);
+  hipLaunchKernelGGL(k_lookup<V>, dim3(grid_for(n, 32 * kIlp)), dim3(256), 0, st, t->d, ids, n, out);
 }
 
 template <int V, int OPTK>
@@ -1107,8 +1180,8 @@ static void launch_long_m(const Table* t, const ApplyArgs& a, unsigned grid, hip
   }
 }
 static void launch_long_o(const Table* t, const ApplyArgs& a, unsigned grid, hipStream_t st) {
-  const unsigned cgrid = (unsigned)std::min<int64_t>(a.n / kChunk + 1, 256);
-  const bool may_split = a.mode != MODE_OPT_SEQ && a.n > kChunk;
+  const unsigned cgrid = (unsigned)std::min<int64_t>(a.n / a.chunk + 1, 256);
+  const bool may_split = a.mode != MODE_OPT_SEQ && a.n > a.chunk;
   switch (t->opt_tmpl) {
     case OPTK_SGD:
       launch_long_m<OPTK_SGD>(t, a, grid, st);
@@ -1134,7 +1207,7 @@ static void launch_short(const Table* t, const ApplyArgs& a, hipStream_t st) {
   else launch_apply_v<4>(t, a, st);
 }
 
-static int launch_apply(Table* t, ApplyArgs& a, uint2* heads, uint32_t* nheads, hipStream_t st) {
+static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, hipStream_t st) {
   const bool walks =
       a.mode == MODE_ASSIGN_ADD || a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP;
   const bool allow_long = walks && a.n > kLongSeg && t->d.dim <= kLongMaxDim;
@@ -1181,6 +1254,14 @@ static int launch_apply(Table* t, ApplyArgs& a, uint2* heads, uint32_t* nheads, 
 
 // Scratch behind the apply kernels: counters, long-segment queue, split-key queue, chunk sums,
 // compacted heads.
+static int chunk_size() {  // MONO_CHUNK: experiment knob, clamped to [256, 1 << 20]
+  static const int v = [] {
+    const char* e = getenv("MONO_CHUNK");
+    int c = e ? atoi(e) : kChunk;
+    return std::max(256, std::min(c, 1 << 20));
+  }();
+  return v;
+}
 struct QueueLayout {
   size_t lq, cq, pt, heads;
 };
@@ -1188,24 +1269,26 @@ static QueueLayout queue_layout(int64_t n, int dim) {
   QueueLayout q;
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
   q.lq = (((size_t)n / kLongSeg + 2) * sizeof(LongSeg) + 255) & ~(size_t)255;
-  q.cq = (((size_t)n / kChunk + 2) * sizeof(SplitSeg) + 255) & ~(size_t)255;
-  q.pt = (((size_t)n / (kChunk / 2) + 2) * (size_t)dim * sizeof(float) + 255) & ~(size_t)255;
-  q.heads = n_al * sizeof(uint2);
+  const size_t chunk = (size_t)chunk_size();
+  q.cq = (((size_t)n / chunk + 2) * sizeof(SplitSeg) + 255) & ~(size_t)255;
+  q.pt = (((size_t)n / (chunk / 2) + 2) * (size_t)dim * sizeof(float) + 255) & ~(size_t)255;
+  q.heads = n_al * sizeof(uint4);
   return q;
 }
 static size_t queue_bytes(int64_t n, int dim) {
   QueueLayout q = queue_layout(n, dim);
   return 256 + q.lq + q.cq + q.pt + q.heads;
 }
-static int queue_setup(ApplyArgs* a, char* q_base, int64_t n, int dim, uint2** heads,
-                       hipStream_t st) {
+static int queue_setup(ApplyArgs* a, char* q_base, int64_t n, int dim, uint4** heads,
+                       hipStream_t st, bool counters_cleared = false) {
   QueueLayout q = queue_layout(n, dim);
+  a->chunk = chunk_size();
   a->qcount = (uint32_t*)q_base;
   a->queue = (LongSeg*)(q_base + 256);
   a->cqueue = (SplitSeg*)(q_base + 256 + q.lq);
   a->partials = (float*)(q_base + 256 + q.lq + q.cq);
-  *heads = (uint2*)(q_base + 256 + q.lq + q.cq + q.pt);
-  MONO_HIP(hipMemsetAsync(a->qcount, 0, 4 * sizeof(uint32_t), st));
+  *heads = (uint4*)(q_base + 256 + q.lq + q.cq + q.pt);
+  if (!counters_cleared) MONO_HIP(hipMemsetAsync(a->qcount, 0, 4 * sizeof(uint32_t), st));
   return 0;
 }
 
@@ -1254,8 +1337,8 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
     uint32_t* slot_out = idx_in + n_al;
     uint32_t* idx_out = slot_out + n_al;
     void* tmp = idx_out + n_al;
-    hipLaunchKernelGGL(k_find_or_claim, dim3(grid_for(n, 32)), dim3(256), 0, st, t->d, ids, n,
-                       slot_in, idx_in);
+    hipLaunchKernelGGL(k_find_or_claim, dim3(grid_for(n, 32 * kIlp)), dim3(256), 0, st, t->d, ids, n,
+                       slot_in, idx_in, (uint32_t*)q_base);
     MONO_HIP(hipGetLastError());
     if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
     MONO_TRY(sort_pairs_u32(slot_in, slot_out, idx_in, idx_out, (size_t)n, end_bit, tmp, tmp_bytes,
@@ -1280,8 +1363,8 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
     a.skeys = key_out;
     a.sidx = idx_out;
   }
-  uint2* heads = nullptr;
-  MONO_TRY(queue_setup(&a, q_base, n, t->d.dim, &heads, st));
+  uint4* heads = nullptr;
+  MONO_TRY(queue_setup(&a, q_base, n, t->d.dim, &heads, st, !from_keys));
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[2], st));
   MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st));
   MONO_HIP(hipGetLastError());
@@ -1318,7 +1401,7 @@ int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, con
   a.src = src;
   a.mode = MODE_ASSIGN_ADD;
   MONO_TRY(t->ws.ensure(queue_bytes(n, D)));
-  uint2* heads = nullptr;
+  uint4* heads = nullptr;
   MONO_TRY(queue_setup(&a, (char*)t->ws.ptr, n, D, &heads, st));
   MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st));
   MONO_HIP(hipGetLastError());
