@@ -1,0 +1,121 @@
+"""GPU, world size 2 on ONE device: the sync-training exchange with the real HIP ops and tables
+on both ranks. torch.distributed's gloo backend carries the all-to-alls (host-staged: two RCCL
+ranks cannot share a GPU); on a multi-GPU node the same code runs over RCCL (bench.py --gpus N).
+Checked against a serial oracle model of every owner shard (source-rank-major application)."""
+import os
+import socket
+import traceback
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+  s = socket.socket()
+  s.bind(("127.0.0.1", 0))
+  p = s.getsockname()[1]
+  s.close()
+  return p
+
+
+def _batch(rank, step):
+  rng = np.random.Generator(np.random.PCG64(1000 * step + rank))
+  ids = {"a": rng.integers(-400, 400, 3000).astype(np.int64),
+         "b": (rng.integers(0, 25, 1200) * 3 + 1).astype(np.int64),
+         "c": np.zeros(0, np.int64)}
+  dims = {"a": 16, "b": 2, "c": 3}
+  grads = {k: rng.normal(0, 0.5, (len(v), dims[k])).astype(np.float32) for k, v in ids.items()}
+  return ids, grads
+
+
+def _worker(rank, world, port, q):
+  try:
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["MONOLITH_SYNC_EMPTY_RANK0_PS_SHARD"] = "1"  # N <= 4: plain floormod either way
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import cpu
+    from monolith_amd import distributed_ps_sync, entry, hash_table_ops, multi_type_hash_table
+
+    def cfg(dim, opt):
+      tc = entry.EmbeddingHashTableConfig(
+          segments=[entry.CombineAsSegment(dim, entry.ZerosInitializer(), opt)])
+      return tc
+    opts = {"a": (16, entry.AdagradOptimizer(initial_accumulator_value=0.1), 0.1),
+            "b": (2, entry.SgdOptimizer(), 0.5),
+            "c": (3, entry.FtrlOptimizer(initial_accumulator_value=0.1, beta=0.0,
+                                         l1_regularization=0.0, l2_regularization=0.0), 0.01)}
+    cfgs = {k: entry.HashTableConfigInstance(cfg(d, o), [lr]) for k, (d, o, lr) in opts.items()}
+    table = distributed_ps_sync.DistributedMultiTypeHashTableMpi(
+        world, lambda idx: multi_type_hash_table.MultiTypeHashTable(
+            cfgs, lambda slot, c: hash_table_ops.hash_table_from_config(
+                c, name_suffix="dg_%s_%d" % (slot, idx))))
+    segs = {"a": cpu.seg(16, "adagrad"), "b": cpu.seg(2, "sgd"), "c": cpu.seg(3, "ftrl")}
+    lrs = {k: v[2] for k, v in opts.items()}
+    model = [{k: cpu.OracleTable([v]) for k, v in segs.items()} for _ in range(world)]
+    for step in range(3):
+      ids, grads = _batch(rank, step)
+      slot_to_ids = {k: torch.from_numpy(v).to(dev) for k, v in ids.items()}
+      emb, bundle = table.lookup(slot_to_ids, auxiliary_bundle={})
+      for k, v in ids.items():
+        exp = np.zeros((len(v), model[0][k].dim), np.float32)
+        for n in range(world):
+          sel = np.mod(v, world) == n
+          if sel.any():
+            exp[sel] = model[n][k].lookup(v[sel])
+        assert np.array_equal(emb[k].cpu().numpy().view(np.uint32), exp.view(np.uint32)), (step, k)
+      table = table.apply_gradients(
+          {k: (slot_to_ids[k], torch.from_numpy(grads[k]).to(dev)) for k in ids},
+          auxiliary_bundle=bundle, global_step=step, req_time=100 + step)
+      for n in range(world):
+        for src in range(world):
+          s_ids, s_grads = _batch(src, step)
+          for k in sorted(s_ids):
+            v, g = s_ids[k], s_grads[k]
+            sel = np.mod(v, world) == n
+            v, g = v[sel], g[sel]
+            uniq, first = np.unique(v, return_index=True)
+            order = uniq[np.argsort(first)]
+            summed = np.zeros((len(order), g.shape[1]), np.float32)
+            for i, u in enumerate(order):
+              acc = np.zeros(g.shape[1], np.float32)
+              for row in g[v == u]:
+                acc = acc + row
+              summed[i] = acc
+            model[n][k].apply_gradients(order, summed, [lrs[k]], req_time=100 + step,
+                                        global_step=step)
+    for k, ht in table._table._hash_tables.items():
+      gi, gr, gt = [x.cpu().numpy() for x in ht.save_as_tensor()]
+      ei, er, et = model[rank][k].export()
+      go, eo = np.argsort(gi, kind="stable"), np.argsort(ei, kind="stable")
+      assert np.array_equal(gi[go], ei[eo]), k
+      assert np.array_equal(gr[go].view(np.uint32), er[eo].view(np.uint32)), k
+      assert np.array_equal(gt[go], et[eo]), k
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, None))
+  except Exception:
+    q.put((rank, traceback.format_exc()))
+
+
+def test_world2_exchange_on_hip_ops():
+  world = 2
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+  for p in ps:
+    p.start()
+  res = [q.get(timeout=150) for _ in ps]
+  for p in ps:
+    p.join(timeout=30)
+  for rank, err in res:
+    assert err is None, "rank %d failed:\n%s" % (rank, err)
