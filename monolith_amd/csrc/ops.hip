@@ -265,11 +265,18 @@ __device__ inline int64_t floormod_dev(int64_t a, int64_t b) {
 // smallest global occurrence index that hit it = the first occurrence.
 __global__ void __launch_bounds__(256) k_reorder_insert(ReorderArgs a, const SlotMeta* sm,
                                                         int64_t* hkeys, uint32_t* hfirst,
-                                                        uint32_t* hcell) {
+                                                        uint32_t* hcell, int phase) {
+  // Two launches. Phase 0 inserts only the first 1/64 of every slot's occurrences, phase 1 the
+  // rest. A hot key (thousands of occurrences) almost surely occurs in that head, so by the time
+  // the bulk runs its cell already holds a small index and the guarded atomicMin below is
+  // skipped; in one launch ~10 k concurrent occurrences of one key would all see the initial
+  // value and serialise on a single word (~90 atomics / us).
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total;
        g += (int64_t)gridDim.x * blockDim.x) {
     const int m = find_slot_of(sm, a.M, g);
     const SlotMeta s = sm[m];
+    const bool head = (g - s.base) < ((s.len + 63) >> 6);
+    if (head != (phase == 0)) continue;
     const int64_t key = s.ids[g - s.base];
     int64_t cell;
     if (key == -1) {
@@ -602,7 +609,8 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   MONO_HIP(hipMemsetAsync(hist, 0, hist_al * 4, st));
   ReorderArgs a{M, N, shard_rule, total};
   const dim3 grid(grid_for(total, 256)), blk(256);
-  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hkeys, hfirst, hcell);
+  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hkeys, hfirst, hcell, 0);
+  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hkeys, hfirst, hcell, 1);
   hipLaunchKernelGGL(k_reorder_keys, grid, blk, 0, st, a, d_sm, hfirst, hcell, skey, sidx);
   MONO_HIP(hipGetLastError());
   MONO_TRY(sort_pairs(skey, skey2, sidx, sidx2, (size_t)total,
