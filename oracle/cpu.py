@@ -428,3 +428,18 @@ def embedding_to_layout_grad(plan_slices, slice_idx_of, max_slice_num, bufs, fid
                                      len(nfl), C.c_int32(batch), _ptr_array(og),
                                      C.c_int(int(mean_divides)))
   return grads
+
+
+def bench_lookup_apply_mt(segments, ids_batches, grads, lr, threads):
+  """bench.py's cpu_baseline: (seconds, rows) of lookup + apply_gradients(dedup) over the batches
+  with `threads` shard-owning threads (orc_bench_lookup_apply_mt)."""
+  cfg, keep = make_table_cfg(segments)
+  ids = np.ascontiguousarray(np.stack([_i64(b) for b in ids_batches]))
+  g = _f32(grads)
+  rows = C.c_int64(0)
+  fn = lib().orc_bench_lookup_apply_mt
+  fn.restype = C.c_double
+  dt = fn(C.byref(cfg), _p(ids), _p(g), C.c_int64(ids.shape[1]), int(ids.shape[0]), C.c_float(lr),
+          int(threads), C.byref(rows))
+  del keep
+  return float(dt), int(rows.value)

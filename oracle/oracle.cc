@@ -21,7 +21,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <chrono>
 #include <memory>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -754,6 +756,63 @@ void orc_adagrad(float* num, float* norm, const float* grad, int64_t len, float 
     float effective_lr = lr / std::sqrt(norm[i]);
     num[i] -= effective_lr * g;
   }
+}
+
+
+// CPU baseline for bench.py (measurement aid, not a parity function): T threads, each owning the
+// table shard of the ids with mix(id) % T == t (no locks, i.e. an upper bound for a striped-lock
+// CPU table such as the reference's). Every thread scans each batch, gathers its own occurrences,
+// looks them up and applies the gradients with dedup. Tables are pre-populated with exactly the
+// ids of the sample (untimed). Returns the wall time of the timed part in seconds.
+double orc_bench_lookup_apply_mt(const TableCfg* cfg, const int64_t* ids, const float* grads,
+                                 int64_t n, int n_batches, float lr, int T, int64_t* rows_out) {
+  std::vector<void*> tabs(T);
+  for (int t = 0; t < T; ++t) tabs[t] = orc_table_create(cfg);
+  const int D = orc_table_dim(tabs[0]);
+  auto shard_of = [T](int64_t id) {
+    uint64_t x = (uint64_t)id;
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL; x ^= x >> 27; x *= 0x94d049bb133111ebULL; x ^= x >> 31;
+    return (int)(x % (uint64_t)T);
+  };
+  auto run = [&](bool populate) {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t)
+      th.emplace_back([&, t] {
+        std::vector<int64_t> my_ids;
+        std::vector<float> my_g, out;
+        for (int b = 0; b < n_batches; ++b) {
+          const int64_t* bid = ids + (int64_t)b * n;
+          my_ids.clear();
+          my_g.clear();
+          for (int64_t i = 0; i < n; ++i)
+            if (shard_of(bid[i]) == t) {
+              my_ids.push_back(bid[i]);
+              if (!populate) my_g.insert(my_g.end(), grads + i * D, grads + (i + 1) * D);
+            }
+          const int64_t m = (int64_t)my_ids.size();
+          if (populate) {
+            my_g.assign((size_t)m * D, 0.f);
+            orc_table_assign_add(tabs[t], nullptr, my_ids.data(), my_g.data(), m, 1);
+          } else {
+            out.resize((size_t)m * D);
+            orc_table_lookup(tabs[t], my_ids.data(), m, out.data());
+            orc_table_apply_gradients(tabs[t], nullptr, my_ids.data(), my_g.data(), m, &lr, 2, b, 1);
+          }
+        }
+      });
+    for (auto& x : th) x.join();
+  };
+  run(true);
+  auto t0 = std::chrono::steady_clock::now();
+  run(false);
+  double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  int64_t rows = 0;
+  for (int t = 0; t < T; ++t) {
+    rows += orc_table_size(tabs[t]);
+    orc_table_destroy(tabs[t]);
+  }
+  if (rows_out) *rows_out = rows;
+  return dt;
 }
 
 }  // extern "C"
