@@ -195,6 +195,21 @@ int mono_fused_sorted_segment_sum(const int32_t* const* indices, const float* co
 int mono_first_n(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
                  int64_t batch, int64_t max_seq, float* out, void* stream);
 
+/* ---- checkpoint framing (host side) ----
+ * The reference writes table dumps with TensorFlow's io::RecordWriter (ops/hash_table_save_op.cc:
+ * 128-165; TensorFlow is a third-party dependency pinned by third_party/org_tensorflow and absent
+ * from the tree): every record is  uint64 length | masked crc32c(length) | data | masked
+ * crc32c(data), mask(c) = ((c >> 15) | (c << 17)) + 0xa282ead8. Pinned by the dump files the
+ * reference ships (model_export/testdata/saved_model/.../assets). Plain host memory, no GPU. */
+uint32_t mono_crc32c(const void* data, int64_t n);
+/* frames n equal-length payloads back to back into out (n * (16 + payload_len) bytes); returns the
+ * bytes written */
+int64_t mono_tfrecord_frame(const uint8_t* payloads, int64_t n, int64_t payload_len, uint8_t* out);
+/* walks a record file image: payload offsets / lengths of up to max_records records; returns the
+ * record count, -1 on a framing or (verify != 0) crc error */
+int64_t mono_tfrecord_scan(const uint8_t* buf, int64_t len, int64_t* offsets, int64_t* lengths,
+                           int64_t max_records, int verify);
+
 /* ---- layout fusion ---- */
 /* One SliceConfig of one layout (idl/matrix/proto/example.proto SliceConfig / OutConfig), flattened
  * by the host exactly as MonolithEmbeddingToLayoutBase's constructor and the Layout classes do

@@ -3,6 +3,10 @@ library raises, and every non-zero status from the C ABI raises MonolithHipError
 import ctypes as C
 import os
 
+# torch must load its HIP runtime before libmonolith_hip.so pulls in libamdhip64: with the order
+# reversed both end up sharing the system copy and torch then reports "No HIP GPUs are available".
+import torch  # noqa: F401  pylint: disable=unused-import
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmonolith_hip.so")
 

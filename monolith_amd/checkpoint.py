@@ -1,0 +1,386 @@
+"""Reference-format table dumps: read / write the files MonolithHashTableSave / Restore produce
+(ops/hash_table_save_op.cc:95-165, ops/hash_table_restore_op.cc:60-150).
+
+  file      <basename>-%05d-of-%05d (save_utils / GetShardedFileName), TFRecord framing
+  record    serialized EntryDump (runtime/hash_table/embedding_hash_table.proto:45-50):
+              1: sfixed64 id            2: repeated float num (NOT packed: one 0x15 tag per value)
+              3: OptimizerDump opt      4: int64 last_update_ts_sec (varint)
+            OptimizerDump.dump[i] = SingleOptimizerDump, one per segment
+            (optimizer.proto:216-236): adagrad = 1 {norm = 1}, sgd = 2 {}, ftrl = 3 {zero = 1, norm = 2}
+
+protobuf is not used: the wire format of these four messages is written / parsed directly, so that
+whole tables convert with numpy (records of one table share one byte layout per timestamp-varint
+length). Pinned byte for byte by the dump files the reference ships
+(tests/golden/ckpt/, from model_export/testdata/saved_model/ps_3/.../assets)."""
+import ctypes as C
+import glob
+import os
+import re
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from monolith_amd import _lib, entry
+
+SGD, ADAGRAD, FTRL = entry.OPT_SGD, entry.OPT_ADAGRAD, entry.OPT_FTRL
+
+
+def sharded_name(basename: str, idx: int, total: int) -> str:
+  return "%s-%05d-of-%05d" % (basename, idx, total)
+
+
+# ----------------------------------------------------------------------------- framing
+def masked_crc32c(data: bytes) -> int:
+  fn = _lib.lib.mono_crc32c
+  fn.restype = C.c_uint32
+  c = fn(data, C.c_int64(len(data)))
+  return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xFFFFFFFF
+
+
+def read_records(path: str, verify: bool = True) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+  """(file image uint8, payload offsets, payload lengths); raises on a bad frame / crc."""
+  buf = np.fromfile(path, dtype=np.uint8)
+  if buf.size == 0:
+    return buf, np.zeros(0, np.int64), np.zeros(0, np.int64)
+  fn = _lib.lib.mono_tfrecord_scan
+  fn.restype = C.c_int64
+  p = C.c_void_p(buf.ctypes.data)
+  n = fn(p, C.c_int64(buf.size), None, None, C.c_int64(0), C.c_int(int(verify)))
+  if n < 0:
+    _lib.check(1)
+  off = np.empty(n, np.int64)
+  ln = np.empty(n, np.int64)
+  fn(p, C.c_int64(buf.size), C.c_void_p(off.ctypes.data), C.c_void_p(ln.ctypes.data), C.c_int64(n),
+     C.c_int(0))
+  return buf, off, ln
+
+
+def frame_records(payloads: np.ndarray) -> np.ndarray:
+  """payloads uint8[n, L] -> framed bytes uint8[n * (L + 16)]."""
+  payloads = np.ascontiguousarray(payloads, dtype=np.uint8)
+  n, L = payloads.shape
+  out = np.empty(n * (L + 16), np.uint8)
+  fn = _lib.lib.mono_tfrecord_frame
+  fn.restype = C.c_int64
+  w = fn(C.c_void_p(payloads.ctypes.data), C.c_int64(n), C.c_int64(L), C.c_void_p(out.ctypes.data))
+  assert w == out.size
+  return out
+
+
+# ----------------------------------------------------------------------------- EntryDump
+def _varint(v: int) -> bytes:
+  v &= (1 << 64) - 1
+  out = bytearray()
+  while True:
+    b = v & 0x7F
+    v >>= 7
+    if v:
+      out.append(b | 0x80)
+    else:
+      out.append(b)
+      return bytes(out)
+
+
+def _read_varint(b, pos):
+  v, shift = 0, 0
+  while True:
+    x = int(b[pos])
+    pos += 1
+    v |= (x & 0x7F) << shift
+    if not x & 0x80:
+      return v, pos
+    shift += 7
+
+
+def _opt_payload_len(kind: int, dim: int) -> int:
+  if kind == SGD:
+    return 0
+  return 5 * dim * (1 if kind == ADAGRAD else 2)
+
+
+def _len_prefixed(tag: int, n: int) -> bytes:
+  return bytes([tag]) + _varint(n)
+
+
+class DumpLayout:
+  """Byte layout of the EntryDump records of one table (segments = [(dim, opt kind)])."""
+
+  def __init__(self, segments: Sequence[Tuple[int, int]]):
+    self.segments = [(int(d), int(k)) for d, k in segments]
+    self.dim = sum(d for d, _ in self.segments)
+    self.state = sum(_opt_payload_len(k, d) // 5 for d, k in self.segments)
+    self.row_floats = self.dim + self.state
+
+  @staticmethod
+  def from_table_config(tc: entry.EmbeddingHashTableConfig) -> "DumpLayout":
+    return DumpLayout([(s.dim_size, s.opt_config.kind) for s in tc.segments])
+
+  # -- template of one record with a ts varint of `ts_len` bytes
+  def _template(self, ts_len: int):
+    """(bytes template, offsets of id / floats (row order) / ts)."""
+    t = bytearray()
+    t += b"\x09" + b"\x00" * 8
+    id_off = 1
+    float_offs = [0] * self.row_floats
+    for i in range(self.dim):
+      t += b"\x15"
+      float_offs[i] = len(t)
+      t += b"\x00" * 4
+    # OptimizerDump
+    singles = []
+    st = self.dim  # row index of the next state float
+    for d, k in self.segments:
+      body = bytearray()
+      marks = []
+      if k == ADAGRAD:
+        for i in range(d):
+          body += b"\x0d"
+          marks.append((len(body), st + i))
+          body += b"\x00" * 4
+        st += d
+        single = _len_prefixed(0x0a, len(body)) + bytes(body)
+        hdr = len(_len_prefixed(0x0a, len(body)))
+      elif k == FTRL:  # row layout: norm[d] | zero[d]; dump: zero = 1, norm = 2
+        for i in range(d):
+          body += b"\x0d"
+          marks.append((len(body), st + d + i))
+          body += b"\x00" * 4
+        for i in range(d):
+          body += b"\x15"
+          marks.append((len(body), st + i))
+          body += b"\x00" * 4
+        st += 2 * d
+        single = _len_prefixed(0x1a, len(body)) + bytes(body)
+        hdr = len(_len_prefixed(0x1a, len(body)))
+      else:
+        single = b"\x12\x00"
+        hdr = 2
+      singles.append((single, hdr, marks))
+    opt = bytearray()
+    opt_marks = []
+    for single, hdr, marks in singles:
+      pre = _len_prefixed(0x0a, len(single))
+      base = len(opt) + len(pre) + hdr
+      for off, row_i in marks:
+        opt_marks.append((base + off, row_i))
+      opt += pre + single
+    pre = _len_prefixed(0x1a, len(opt))
+    base = len(t) + len(pre)
+    for off, row_i in opt_marks:
+      float_offs[row_i] = base + off
+    t += pre + opt
+    t += b"\x20"
+    ts_off = len(t)
+    t += b"\x00" * ts_len
+    return bytes(t), id_off, np.array(float_offs, np.int64), ts_off
+
+  def encode(self, ids: np.ndarray, rows: np.ndarray, ts: np.ndarray) -> List[np.ndarray]:
+    """Serialized records, grouped by record length: list of uint8[n_g, L_g] (input order kept
+    inside a group)."""
+    ids = np.asarray(ids, np.int64)
+    rows = np.ascontiguousarray(rows, np.float32).reshape(len(ids), self.row_floats)
+    ts = np.asarray(ts).astype(np.uint64)
+    vlen = np.ones(len(ids), np.int64)
+    for k in range(1, 10):
+      vlen += (ts >= (1 << (7 * k))).astype(np.int64)
+    out = []
+    for L in np.unique(vlen):
+      sel = np.nonzero(vlen == L)[0]
+      tmpl, id_off, f_offs, ts_off = self._template(int(L))
+      rec = np.tile(np.frombuffer(tmpl, np.uint8), (len(sel), 1))
+      rec[:, id_off:id_off + 8] = ids[sel].view(np.uint8).reshape(-1, 8)
+      fb = rows[sel].view(np.uint8).reshape(len(sel), self.row_floats, 4)
+      for j in range(4):
+        rec[:, f_offs + j] = fb[:, :, j]
+      t = ts[sel].copy()
+      for j in range(int(L)):
+        b = (t & 0x7F).astype(np.uint8)
+        t >>= np.uint64(7)
+        if j < int(L) - 1:
+          b |= 0x80
+        rec[:, ts_off + j] = b
+      out.append(rec)
+    return out
+
+  def decode(self, buf: np.ndarray, off: np.ndarray, ln: np.ndarray):
+    """(ids int64[n], rows float32[n, row_floats], ts uint32[n]) of the records; records whose
+    bytes follow this table's template are converted with numpy, anything else (missing ts,
+    reordered or unknown fields) record by record."""
+    n = len(off)
+    ids = np.empty(n, np.int64)
+    rows = np.zeros((n, self.row_floats), np.float32)
+    ts = np.zeros(n, np.uint32)
+    done = np.zeros(n, bool)
+    for ts_len in range(1, 6):
+      tmpl, id_off, f_offs, ts_off = self._template(ts_len)
+      sel = np.nonzero((ln == len(tmpl)) & ~done)[0]
+      if not len(sel):
+        continue
+      rec = buf[off[sel][:, None] + np.arange(len(tmpl))[None, :]]
+      mask = np.ones(len(tmpl), bool)
+      mask[id_off:id_off + 8] = False
+      for j in range(4):
+        mask[f_offs + j] = False
+      mask[ts_off:ts_off + ts_len] = False
+      ok = (rec[:, mask] == np.frombuffer(tmpl, np.uint8)[mask]).all(axis=1)
+      tb = rec[:, ts_off:ts_off + ts_len]
+      ok &= (tb[:, :-1] & 0x80).all(axis=1) & ((tb[:, -1] & 0x80) == 0)
+      good = sel[ok]
+      rec = rec[ok]
+      ids[good] = rec[:, id_off:id_off + 8].copy().view(np.int64).reshape(-1)
+      fb = np.empty((len(good), self.row_floats, 4), np.uint8)
+      for j in range(4):
+        fb[:, :, j] = rec[:, f_offs + j]
+      rows[good] = fb.view(np.float32).reshape(len(good), self.row_floats)
+      t = np.zeros(len(good), np.uint64)
+      for j in range(ts_len):
+        t |= (rec[:, ts_off + j] & 0x7F).astype(np.uint64) << np.uint64(7 * j)
+      ts[good] = t.astype(np.uint32)
+      done[good] = True
+    for i in np.nonzero(~done)[0]:
+      ids[i], rows[i], ts[i] = self._decode_one(buf[off[i]:off[i] + ln[i]])
+    return ids, rows, ts
+
+  def _decode_one(self, b):
+    """Generic EntryDump parse of one record (any field order, packed or unpacked floats)."""
+    import struct
+    b = bytes(b)
+    rid, nums, opt, ts = 0, [], b"", 0
+
+    def floats(body, want_fields):
+      res: Dict[int, List[float]] = {f: [] for f in want_fields}
+      pos = 0
+      while pos < len(body):
+        tag, pos = _read_varint(body, pos)
+        f, wt = tag >> 3, tag & 7
+        if wt == 5:
+          v = struct.unpack_from("<f", body, pos)[0]
+          pos += 4
+          if f in res:
+            res[f].append(v)
+        elif wt == 2:
+          n, pos = _read_varint(body, pos)
+          if f in res:
+            res[f].extend(struct.unpack_from("<%df" % (n // 4), body, pos))
+          pos += n
+        elif wt == 0:
+          _, pos = _read_varint(body, pos)
+        elif wt == 1:
+          pos += 8
+        else:
+          raise ValueError("unsupported wire type %d" % wt)
+      return res
+
+    pos = 0
+    while pos < len(b):
+      tag, pos = _read_varint(b, pos)
+      f, wt = tag >> 3, tag & 7
+      if f == 1 and wt == 1:
+        rid = struct.unpack_from("<q", b, pos)[0]
+        pos += 8
+      elif f == 2 and wt == 5:
+        nums.append(struct.unpack_from("<f", b, pos)[0])
+        pos += 4
+      elif f == 2 and wt == 2:
+        n, pos = _read_varint(b, pos)
+        nums.extend(struct.unpack_from("<%df" % (n // 4), b, pos))
+        pos += n
+      elif f == 3 and wt == 2:
+        n, pos = _read_varint(b, pos)
+        opt = b[pos:pos + n]
+        pos += n
+      elif f == 4 and wt == 0:
+        ts, pos = _read_varint(b, pos)
+      elif wt == 0:
+        _, pos = _read_varint(b, pos)
+      elif wt == 2:
+        n, pos = _read_varint(b, pos)
+        pos += n
+      elif wt == 5:
+        pos += 4
+      elif wt == 1:
+        pos += 8
+      else:
+        raise ValueError("unsupported wire type %d" % wt)
+    if len(nums) != self.dim:
+      raise ValueError("EntryDump of id %d has %d values, the table expects %d" %
+                       (rid, len(nums), self.dim))
+    row = np.zeros(self.row_floats, np.float32)
+    row[:self.dim] = nums
+    singles = []
+    pos = 0
+    while pos < len(opt):
+      tag, pos = _read_varint(opt, pos)
+      n, pos = _read_varint(opt, pos)
+      if tag >> 3 == 1:
+        singles.append(opt[pos:pos + n])
+      pos += n
+    if len(singles) != len(self.segments):
+      raise ValueError("EntryDump of id %d has %d optimizer dumps, the table has %d segments" %
+                       (rid, len(singles), len(self.segments)))
+    st = self.dim
+    for (d, k), single in zip(self.segments, singles):
+      tag, p2 = _read_varint(single, 0) if single else (0, 0)
+      n, p2 = _read_varint(single, p2) if single else (0, 0)
+      body = single[p2:p2 + n]
+      kind_field = tag >> 3
+      if k == ADAGRAD:
+        if kind_field != 1:
+          raise ValueError("segment expects an adagrad dump, found field %d" % kind_field)
+        row[st:st + d] = floats(body, [1])[1]
+        st += d
+      elif k == FTRL:
+        if kind_field != 3:
+          raise ValueError("segment expects an ftrl dump, found field %d" % kind_field)
+        r = floats(body, [1, 2])
+        row[st:st + d] = r[2]
+        row[st + d:st + 2 * d] = r[1]
+        st += 2 * d
+      elif kind_field != 2:
+        raise ValueError("segment expects an sgd dump, found field %d" % kind_field)
+    return rid, row, np.uint32(ts & 0xFFFFFFFF)
+
+
+# ----------------------------------------------------------------------------- table level
+def pick_nshards(size: int, nshards: int = -1) -> int:
+  """HashTableSaveOp::PickNshards (hash_table_save_op.cc:116-121)."""
+  if nshards >= 0:
+    return nshards
+  return int(min(4, max(1, size // 1000000)))
+
+
+def write_shards(basename: str, layout: DumpLayout, ids, rows, ts, nshards: int):
+  """Writes <basename>-%05d-of-%05d; rows go to shard floormod(id, nshards) (the reference's
+  split follows its cuckoo buckets and is unobservable; restore reads every shard)."""
+  os.makedirs(os.path.dirname(os.path.abspath(basename)), exist_ok=True)
+  ids = np.asarray(ids, np.int64)
+  shard = np.mod(ids, nshards) if nshards > 1 else np.zeros(len(ids), np.int64)
+  for i in range(nshards):
+    sel = np.nonzero(shard == i)[0]
+    name = sharded_name(basename, i, nshards)
+    tmp = "%s-tmp-%d" % (name, os.getpid())
+    with open(tmp, "wb") as f:
+      if len(sel):
+        for group in layout.encode(ids[sel], np.asarray(rows)[sel], np.asarray(ts)[sel]):
+          frame_records(group).tofile(f)
+    os.replace(tmp, name)  # RenameFile(tmp, final), hash_table_save_op.cc:163
+
+
+def read_shards(basename: str, layout: DumpLayout, verify: bool = True):
+  """All records of <basename>-*-of-* (ValidateShardedFiles: a complete, consistent set)."""
+  files = sorted(f for f in glob.glob(glob.escape(basename) + "-*")
+                 if re.fullmatch(r".*-\d{5}-of-\d{5}", f))
+  if not files:
+    raise FileNotFoundError("Unable to find the dump files for: " + basename)
+  totals = {int(f[-5:]) for f in files}
+  if len(totals) != 1 or len(files) != totals.pop():
+    raise ValueError("inconsistent shard files for " + basename)
+  parts = []
+  for f in files:
+    buf, off, ln = read_records(f, verify)
+    if len(off):
+      parts.append(layout.decode(buf, off, ln))
+  if not parts:
+    return (np.zeros(0, np.int64), np.zeros((0, layout.row_floats), np.float32),
+            np.zeros(0, np.uint32))
+  return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))

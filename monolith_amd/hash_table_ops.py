@@ -106,6 +106,7 @@ class _TableResource:
                         table_config.initial_capacity, n, 0, sl, dd, table_config.seed)
     self.h = C.c_void_p()
     self.filter = hash_filter
+    self.config = table_config
     _lib.check(_lib.lib.mono_table_create(C.byref(cfg), C.byref(self.h)))
     self.dim = _lib.lib.mono_table_dim(self.h)
     self.row_floats = _lib.lib.mono_table_row_floats(self.h)
@@ -287,6 +288,33 @@ class HashTable(BaseHashTable):
     _lib.check(_lib.lib.mono_table_import(self._h(), _lib.vp(ids), _lib.vp(rows), _lib.vp(ts),
                                           C.c_int64(ids.numel()), _lib.stream_ptr()))
     return self._copy_with_new_table(self._table)
+
+
+def _save_restore_methods():
+  """save / restore in the reference's on-disk format (hash_table_ops.py:313-333 ->
+  ops/hash_table_save_op.cc / hash_table_restore_op.cc), through monolith_amd.checkpoint."""
+  from monolith_amd import checkpoint
+
+  def save(self, basename: str, random_sleep_ms: int = 0) -> "HashTable":
+    # save-time expiry: rows older than their slot's expire time are skipped (:142-150)
+    ids, rows, ts = self.save_as_tensor(apply_expiry=True)
+    layout = checkpoint.DumpLayout.from_table_config(self._table.config)
+    nshards = checkpoint.pick_nshards(int(ids.numel()), self._saver_parallel)
+    checkpoint.write_shards(str(basename), layout, ids.cpu().numpy(), rows.cpu().numpy(),
+                            ts.cpu().numpy().astype("uint32"), max(1, nshards))
+    return self._copy_with_new_table(self._table)
+
+  def restore(self, basename: str) -> "HashTable":
+    layout = checkpoint.DumpLayout.from_table_config(self._table.config)
+    ids, rows, ts = checkpoint.read_shards(str(basename), layout)
+    return self.restore_from_tensor(torch.from_numpy(ids), torch.from_numpy(rows),
+                                    torch.from_numpy(ts.astype("int64")))
+
+  HashTable.save = save
+  HashTable.restore = restore
+
+
+_save_restore_methods()
 
 
 def _handles(tables):
