@@ -6,6 +6,7 @@ device buffers. TF graph / proto / saver-listener plumbing is not reproduced (SU
 """
 import abc
 import copy
+import os
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
@@ -315,6 +316,40 @@ def _save_restore_methods():
 
 
 _save_restore_methods()
+
+
+def _all_table_tensor_prefix(table: HashTable) -> List[str]:
+  """hash_table_ops.py:554-556."""
+  all_names = [table.name] + list(table.extra_restore_names)
+  return [name.replace(":", "-").replace("/", "-") for name in all_names]
+
+
+def save_hash_tables(asset_dir: str, tables: Sequence[HashTable]) -> None:
+  """What HashTableCheckpointSaverListener.before_save does for every table of the graph
+  collection (hash_table_ops.py:573-590): each table is dumped to
+  <asset_dir><table name with ':' and '/' replaced by '-'>-%05d-of-%05d. `asset_dir` is used as a
+  string prefix, exactly like the reference (it ends with '/')."""
+  d = os.path.dirname(asset_dir)
+  if d:
+    os.makedirs(d, exist_ok=True)
+  for t in tables:
+    t.save(asset_dir + _all_table_tensor_prefix(t)[0])
+
+
+def restore_hash_tables(asset_dir: str, tables: Sequence[HashTable]) -> None:
+  """HashTableCheckpointRestorerListener._restore_from_path_prefix (hash_table_ops.py:645-679):
+  the first of [name] + extra_restore_names that has dump files under the prefix is restored;
+  none -> ValueError (model structure changed)."""
+  import glob
+  for t in tables:
+    prefixes = _all_table_tensor_prefix(t)
+    for prefix in prefixes:
+      if glob.glob(glob.escape(asset_dir + prefix) + "*"):
+        t.restore(asset_dir + prefix)
+        break
+    else:
+      raise ValueError("Unable to find table checkpoint in '%s' for table: %r. Maybe the model "
+                       "structure has been changed." % (asset_dir, prefixes))
 
 
 def _handles(tables):

@@ -138,3 +138,114 @@ def test_restore_reference_dumps_into_hip_table_and_save_again(tmp_path):
     o1, o2 = np.argsort(ids), np.argsort(i2)
     assert np.array_equal(ids[o1], i2[o2]) and np.array_equal(ts[o1], t2[o2])
     assert np.array_equal(rows[o1].view(np.uint32), r2[o2].view(np.uint32))
+
+
+# ------------------------------------------------ the reference's own save / restore scenarios
+def _ids_t(x):
+  import torch
+  return torch.tensor(x, dtype=torch.int64, device="cuda:0")
+
+
+def _f(x):
+  import torch
+  return torch.tensor(x, dtype=torch.float32, device="cuda:0")
+
+
+@pytest.mark.gpu
+def test_save_restore(tmp_path):
+  """hash_table_ops_test.py:262-277 (negative id included) + :468-475 (missing files raise)."""
+  from monolith_amd.hash_table_ops import test_hash_table as make
+  t = make(1).assign_add(_ids_t([-1, 1]), _f([[1], [2]]))
+  base = str(tmp_path / "test_save_restore" / "table")
+  t.save(base)
+  t2 = make(1, False).restore(base)
+  assert t2.lookup(_ids_t([-1, 1])).cpu().tolist() == [[1.0], [2.0]]
+  with pytest.raises(Exception):
+    make(1).restore(str(tmp_path / "test_restore_not_found" / "table"))
+
+
+@pytest.mark.gpu
+def test_restore_clears_first(tmp_path):
+  """ops/hash_table_restore_op.cc:82: rows present before a restore do not survive it."""
+  from monolith_amd.hash_table_ops import test_hash_table as make
+  base = str(tmp_path / "table")
+  make(1).assign(_ids_t([1]), _f([[1]])).save(base)
+  t2 = make(1).assign(_ids_t([1, 7]), _f([[5], [7]]))
+  t2 = t2.restore(base)
+  assert t2.size() == 1
+  assert t2.lookup(_ids_t([1, 7])).cpu().tolist() == [[1.0], [0.0]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["assign_add", "apply_gradients"])
+def test_save_restore_with_feature_eviction(tmp_path, mode):
+  """hash_table_ops_test.py:294-329 / :331-379: expiry is applied while dumping, against the
+  largest req_time the table has seen."""
+  from monolith_amd.hash_table_ops import test_hash_table as make
+  expire_time = 1
+  t = make(dim_size=1, expire_time=expire_time)
+  max_ts = 10000000
+  sec = expire_time * 24 * 3600
+  for fid, ts in ((1, max_ts - sec - 1), (2, max_ts - sec + 1), (3, max_ts)):
+    if mode == "assign_add":
+      t = t.assign_add(_ids_t([fid]), _f([[fid]]), ts)
+    else:
+      t = t.apply_gradients(_ids_t([fid]), _f([[fid]]), 0, req_time=ts)
+  base = str(tmp_path / mode / "table")
+  t.save(base)
+  t2 = make(1, False).restore(base)
+  sign = 1.0 if mode == "assign_add" else -1.0
+  assert t2.lookup(_ids_t([1, 2, 3])).cpu().tolist() == [[0.0], [sign * 2], [sign * 3]]
+
+
+@pytest.mark.gpu
+def test_entry_ttl(tmp_path):
+  """hash_table_ops_test.py:381-411: expire_time 0 drops everything at save, 3600 days keeps."""
+  from monolith_amd.hash_table_ops import test_hash_table as make
+  for days, expect in ((0, [[0.0], [0.0]]), (60 * 60, [[1.0], [2.0]])):
+    base = str(tmp_path / ("ttl_%d" % days) / "table")
+    make(1, expire_time=days).assign_add(_ids_t([-1, 1]), _f([[1], [2]])).save(base)
+    assert make(1).restore(base).lookup(_ids_t([-1, 1])).cpu().tolist() == expect
+
+
+@pytest.mark.gpu
+def test_entry_ttl_by_slots(tmp_path):
+  """hash_table_ops_test.py:413-466: slot 1 expires after 0 days, slot 2 after 1 day."""
+  from monolith_amd import hash_filter_ops, hash_table_ops as ops
+  tc = entry.EmbeddingHashTableConfig(
+      segments=[entry.CombineAsSegment(1, entry.ZerosInitializer(), entry.SgdOptimizer())])
+  tc.slot_expire_time_config.default_expire_time = 60 * 60
+  tc.slot_expire_time_config.slot_expire_times[1] = 0
+  tc.slot_expire_time_config.slot_expire_times[2] = 1
+  filters = hash_filter_ops.create_hash_filters(0, False)
+  config = entry.HashTableConfigInstance(tc, [1.0])
+  id_1, id_2 = 1 << 48, 2 << 48
+  base, base_new = str(tmp_path / "table"), str(tmp_path / "table_new")
+  t = ops.hash_table_from_config(config, hash_filter=filters[0], name_suffix="ttl_slots_a")
+  t.assign_add(_ids_t([id_1, id_2]), _f([[1], [2]]), 100).save(base)
+  t2 = ops.hash_table_from_config(config, hash_filter=filters[0], name_suffix="ttl_slots_b")
+  t2 = t2.restore(base)
+  assert t2.lookup(_ids_t([id_1, id_2])).cpu().tolist() == [[0.0], [2.0]]
+  t2.save(base_new)
+  t3 = ops.test_hash_table(1).restore(base_new)
+  assert t3.lookup(_ids_t([id_1, id_2])).cpu().tolist() == [[0.0], [2.0]]
+
+
+@pytest.mark.gpu
+def test_checkpoint_dir_helpers_and_extra_restore_names(tmp_path):
+  """The saver / restorer listeners' file naming (hash_table_ops.py:554-556, :573-590, :645-679):
+  <asset_dir><table name>, falling back to extra_restore_names
+  (hash_table_ops_test.py:279-292); unknown table -> ValueError."""
+  from monolith_amd import hash_table_ops as ops
+  asset_dir = str(tmp_path / "model.ckpt-10.assets") + "/"
+  t1 = ops.test_hash_table(1, name_suffix="old/name:0").assign(_ids_t([1]), _f([[1]]))
+  ops.save_hash_tables(asset_dir, [t1])
+  files = sorted(os.listdir(asset_dir))
+  assert files and all(f.startswith(t1.name.replace(":", "-").replace("/", "-") + "-0")
+                       for f in files)
+  t2 = ops.test_hash_table(1, name_suffix="renamed", extra_restore_names=[t1.name])
+  ops.restore_hash_tables(asset_dir, [t2])
+  assert t2.lookup(_ids_t([1])).cpu().tolist() == [[1.0]]
+  t3 = ops.test_hash_table(1, name_suffix="never_saved")
+  with pytest.raises(ValueError):
+    ops.restore_hash_tables(asset_dir, [t3])
