@@ -79,6 +79,17 @@ int mono_filter_intercept_gradient(void* filter, const int64_t* ids, const float
  * block_total_size, num_elements[0..n_blocks)}; synchronises the stream. */
 int mono_filter_state(void* filter, int64_t* h_out, int64_t h_out_len, void* stream);
 
+/* Filter checkpoints: ops/hash_filter_save_op.cc:73-105, ops/hash_filter_restore_op.cc:75-110,
+ * runtime/neo_filter/hash_filter.cc:27-78, sliding_hash_filter.cc:157-213. One call per block
+ * ("split"); h_cells is HOST memory holding the block's whole cell vector (block_total_size + 64
+ * cells); num_elements as the reference's HashFilterSplitMetaDump carries it. */
+int mono_filter_export_split(void* filter, int split, uint16_t* h_cells, int64_t n_cells,
+                             int64_t* h_num_elements, void* stream);
+int mono_filter_import_split(void* filter, int split, const uint16_t* h_cells, int64_t n_cells,
+                             int64_t num_elements, void* stream);
+int mono_filter_set_state(void* filter, int64_t head, int64_t head_increment, int64_t failure_count,
+                          void* stream);
+
 /* ---- table lifetime: ops/hash_table_op.cc:38-131, ops/embedding_hash_table_tf_bridge.cc:48-104 ---- */
 int mono_table_create(const mono_table_cfg* cfg, void** out_table);
 int mono_table_destroy(void* table);

@@ -384,3 +384,173 @@ def read_shards(basename: str, layout: DumpLayout, verify: bool = True):
     return (np.zeros(0, np.int64), np.zeros((0, layout.row_floats), np.float32),
             np.zeros(0, np.uint32))
   return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+
+
+# ============================================================================ hash-filter dumps
+# ops/hash_filter_save_op.cc:73-105: one file per block ("split") of the sliding filter,
+# <basename>-%05d-of-%05d with total = split_num; record 0 = HashFilterSplitMetaDump, then
+# HashFilterSplitDataDump records of at most 10000 cells (hash_filter.cc:25-56).
+#   HashFilterSplitMetaDump   (embedding_hash_table.proto:122-128)  1: uint64 failure_count
+#       2: uint64 total_size  3: uint64 num_elements  4: double fill_rate  5: SlidingHashFilterMetaDump
+#   SlidingHashFilterMetaDump (:108-116)  1: split_num 2: max_forward_step 3: max_backward_step
+#       4: max_step 5: head 6: head_increment (uint32)  7: uint64 failure_count
+#   HashFilterSplitDataDump   (:130-133)  1: uint32 offset  2: repeated uint32 data (proto2: NOT
+#       packed, one 0x10 tag per cell)
+# proto2 writes every field that was set, zero or not; the reference sets them all.
+FILTER_CELLS_PER_RECORD = 10000
+_SLIDING_FIELDS = ("split_num", "max_forward_step", "max_backward_step", "max_step", "head",
+                   "head_increment", "failure_count")
+
+
+def _read_varint(b: bytes, p: int) -> Tuple[int, int]:
+  v = shift = 0
+  while True:
+    if p >= len(b):
+      raise ValueError("truncated varint")
+    c = b[p]
+    p += 1
+    v |= (c & 0x7F) << shift
+    if c < 0x80:
+      return v, p
+    shift += 7
+    if shift > 63:
+      raise ValueError("varint too long")
+
+
+def _parse_fields(b: bytes):
+  """Generic proto wire parser: yields (field number, wire type, value)."""
+  p = 0
+  while p < len(b):
+    tag, p = _read_varint(b, p)
+    fno, wt = tag >> 3, tag & 7
+    if wt == 0:
+      v, p = _read_varint(b, p)
+    elif wt == 1:
+      v, p = b[p:p + 8], p + 8
+    elif wt == 5:
+      v, p = b[p:p + 4], p + 4
+    elif wt == 2:
+      n, p = _read_varint(b, p)
+      v, p = b[p:p + n], p + n
+    else:
+      raise ValueError("unsupported wire type %d" % wt)
+    if p > len(b):
+      raise ValueError("truncated field %d" % fno)
+    yield fno, wt, v
+
+
+def encode_filter_meta(meta: Dict) -> bytes:
+  import struct
+  sl = b"".join(bytes([(i + 1) << 3]) + _varint(meta["sliding"][k])
+                for i, k in enumerate(_SLIDING_FIELDS))
+  return (b"\x08" + _varint(meta["failure_count"]) + b"\x10" + _varint(meta["total_size"]) +
+          b"\x18" + _varint(meta["num_elements"]) + b"\x21" + struct.pack("<d", meta["fill_rate"]) +
+          b"\x2a" + _varint(len(sl)) + sl)
+
+
+def decode_filter_meta(b: bytes) -> Dict:
+  import struct
+  meta = {"failure_count": 0, "total_size": 0, "num_elements": 0, "fill_rate": 0.0,
+          "sliding": {k: 0 for k in _SLIDING_FIELDS}}
+  names = {1: "failure_count", 2: "total_size", 3: "num_elements"}
+  for fno, wt, v in _parse_fields(bytes(b)):
+    if fno in names and wt == 0:
+      meta[names[fno]] = v
+    elif fno == 4 and wt == 1:
+      meta["fill_rate"] = struct.unpack("<d", v)[0]
+    elif fno == 5 and wt == 2:
+      for f2, w2, v2 in _parse_fields(v):
+        if 1 <= f2 <= 7 and w2 == 0:
+          meta["sliding"][_SLIDING_FIELDS[f2 - 1]] = v2
+  return meta
+
+
+def encode_filter_data(offset: int, cells: np.ndarray) -> bytes:
+  """One HashFilterSplitDataDump: offset + the cells, each as tag 0x10 + varint."""
+  c = np.ascontiguousarray(cells, dtype=np.uint32)
+  nb = 1 + (c >= 0x80).astype(np.int64) + (c >= 0x4000).astype(np.int64) + \
+      (c >= 0x200000).astype(np.int64) + (c >= 0x10000000).astype(np.int64)
+  start = np.zeros(len(c) + 1, np.int64)
+  np.cumsum(nb + 1, out=start[1:])
+  out = np.empty(int(start[-1]), np.uint8)
+  out[start[:-1]] = 0x10
+  for k in range(5):
+    sel = nb > k
+    if not sel.any():
+      break
+    byte = (c[sel] >> np.uint32(7 * k)) & np.uint32(0x7F)
+    byte |= np.where(nb[sel] > k + 1, 0x80, 0).astype(np.uint32)
+    out[start[:-1][sel] + 1 + k] = byte.astype(np.uint8)
+  return b"\x08" + _varint(offset) + out.tobytes()
+
+
+def decode_filter_data(b) -> Tuple[int, np.ndarray]:
+  a = np.frombuffer(bytes(b), np.uint8)
+  if a.size == 0:
+    return 0, np.zeros(0, np.uint32)
+  ends = np.flatnonzero(a < 0x80)
+  if ends.size == 0 or ends[-1] != a.size - 1 or ends.size % 2:
+    raise ValueError("corrupt HashFilterSplitDataDump")
+  starts = np.concatenate([[0], ends[:-1] + 1])
+  pos = np.arange(a.size) - np.repeat(starts, ends - starts + 1)
+  if pos.max() > 9:
+    raise ValueError("corrupt HashFilterSplitDataDump (varint too long)")
+  vals = np.add.reduceat((a & 0x7F).astype(np.uint64) << (7 * pos).astype(np.uint64), starts)
+  tags, vals = vals[0::2], vals[1::2]
+  if np.any((ends - starts)[0::2] != 0) or not np.all((tags == 0x08) | (tags == 0x10)):
+    # packed or unknown fields: take the slow generic parser
+    off, data = 0, []
+    for fno, wt, v in _parse_fields(bytes(b)):
+      if fno == 1 and wt == 0:
+        off = v
+      elif fno == 2 and wt == 0:
+        data.append(v)
+      elif fno == 2 and wt == 2:
+        p = 0
+        while p < len(v):
+          x, p = _read_varint(v, p)
+          data.append(x)
+    return int(off), np.array(data, np.uint32)
+  off = vals[tags == 0x08]
+  return (int(off[-1]) if off.size else 0), vals[tags == 0x10].astype(np.uint32)
+
+
+def write_filter_split(path: str, meta: Dict, cells: np.ndarray) -> None:
+  """hash_filter.cc:27-56 through ops/hash_filter_save_op.cc:73-105 (tmp file + rename)."""
+  recs = [encode_filter_meta(meta)]
+  for s in range(0, len(cells), FILTER_CELLS_PER_RECORD):
+    recs.append(encode_filter_data(s, cells[s:s + FILTER_CELLS_PER_RECORD]))
+  os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+  tmp = "%s-tmp-%d" % (path, int.from_bytes(os.urandom(8), "little"))
+  with open(tmp, "wb") as f:
+    for r in recs:
+      f.write(frame_records(np.frombuffer(r, np.uint8).reshape(1, -1)).tobytes())
+  os.replace(tmp, path)
+
+
+def read_filter_split(path: str, verify: bool = True) -> Tuple[Dict, np.ndarray]:
+  """(meta, cells uint16[total_size + 64]) — hash_filter.cc:60-78: cells start zeroed and every
+  data record overwrites [offset, offset + len)."""
+  buf, off, ln = read_records(path, verify)
+  if not len(off):
+    raise ValueError("empty hash filter dump: " + path)
+  meta = decode_filter_meta(buf[off[0]:off[0] + ln[0]].tobytes())
+  cells = np.zeros(int(meta["total_size"]) + 64, np.uint16)
+  for i in range(1, len(off)):
+    o, data = decode_filter_data(buf[off[i]:off[i] + ln[i]].tobytes())
+    if o + len(data) > len(cells):
+      raise ValueError("hash filter dump %s: data beyond total_size + 64" % path)
+    cells[o:o + len(data)] = data.astype(np.uint16)
+  return meta, cells
+
+
+def filter_files(basename: str) -> List[str]:
+  """Complete, consistent shard set of <basename>-*-of-* (file_utils.cc ValidateShardedFiles)."""
+  files = sorted(f for f in glob.glob(glob.escape(basename) + "-*")
+                 if re.fullmatch(r".*-\d{5}-of-\d{5}", f))
+  if not files:
+    raise FileNotFoundError("Unable to find the dump files for: " + basename)
+  totals = {int(f[-5:]) for f in files}
+  if len(totals) != 1 or len(files) != totals.pop():
+    raise ValueError("inconsistent shard files for " + basename)
+  return files

@@ -275,4 +275,62 @@ int mono_filter_state(void* filter, int64_t* h_out, int64_t h_out_len, void* str
   return 0;
 }
 
+// One block ("split") of a sliding filter as the reference dumps it: the block's whole cell
+// vector map_ (total_size + 64 cells, hash_filter.cc:44-56) to / from HOST memory.
+int mono_filter_export_split(void* filter, int split, uint16_t* h_cells, int64_t n_cells,
+                             int64_t* h_num_elements, void* stream) {
+  MONO_REQUIRE(filter && h_cells, "mono_filter_export_split: null argument");
+  Filter* f = (Filter*)filter;
+  MONO_REQUIRE(f->kind == 1, "mono_filter_export_split: not a sliding filter");
+  MONO_REQUIRE(split >= 0 && (uint32_t)split < f->d.n_blocks,
+               "mono_filter_export_split: split %d of %u", split, f->d.n_blocks);
+  MONO_REQUIRE((uint64_t)n_cells == f->d.stride, "mono_filter_export_split: %lld cells, block has %llu",
+               (long long)n_cells, (unsigned long long)f->d.stride);
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t ne = 0;
+  MONO_HIP(hipMemcpyAsync(h_cells, f->d.cells + (size_t)split * f->d.stride, (size_t)n_cells * 2,
+                          hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipMemcpyAsync(&ne, f->d.num_elements + split, 4, hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  if (h_num_elements) *h_num_elements = (int64_t)std::min<uint64_t>(ne, f->d.capacity);
+  return 0;
+}
+
+// HashFilter::Restore (hash_filter.cc:60-78) for one block.
+int mono_filter_import_split(void* filter, int split, const uint16_t* h_cells, int64_t n_cells,
+                             int64_t num_elements, void* stream) {
+  MONO_REQUIRE(filter && h_cells, "mono_filter_import_split: null argument");
+  Filter* f = (Filter*)filter;
+  MONO_REQUIRE(f->kind == 1, "mono_filter_import_split: not a sliding filter");
+  MONO_REQUIRE(split >= 0 && (uint32_t)split < f->d.n_blocks,
+               "mono_filter_import_split: split %d of %u", split, f->d.n_blocks);
+  MONO_REQUIRE((uint64_t)n_cells == f->d.stride, "mono_filter_import_split: %lld cells, block has %llu",
+               (long long)n_cells, (unsigned long long)f->d.stride);
+  MONO_REQUIRE(num_elements >= 0, "mono_filter_import_split: negative num_elements");
+  hipStream_t st = (hipStream_t)stream;
+  const uint32_t ne = (uint32_t)std::min<uint64_t>((uint64_t)num_elements, f->d.capacity);
+  MONO_HIP(hipMemcpyAsync(f->d.cells + (size_t)split * f->d.stride, h_cells, (size_t)n_cells * 2,
+                          hipMemcpyHostToDevice, st));
+  MONO_HIP(hipMemcpyAsync(f->d.num_elements + split, &ne, 4, hipMemcpyHostToDevice, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+// SlidingHashFilter::RestoreMetaDump (sliding_hash_filter.cc:187-201): head, head_increment,
+// failure_count.
+int mono_filter_set_state(void* filter, int64_t head, int64_t head_increment, int64_t failure_count,
+                          void* stream) {
+  MONO_REQUIRE(filter, "mono_filter_set_state: null filter");
+  Filter* f = (Filter*)filter;
+  MONO_REQUIRE(f->kind == 1, "mono_filter_set_state: not a sliding filter");
+  MONO_REQUIRE(head >= 0 && (uint64_t)head < f->d.n_blocks, "mono_filter_set_state: head %lld of %u",
+               (long long)head, f->d.n_blocks);
+  hipStream_t st = (hipStream_t)stream;
+  uint32_t state[4] = {(uint32_t)head, (uint32_t)head_increment, (uint32_t)failure_count, 0};
+  MONO_HIP(hipMemcpyAsync(f->d.state, state, 16, hipMemcpyHostToDevice, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  return 0;
+}
+
+
 }  // extern "C"

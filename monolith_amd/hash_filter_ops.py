@@ -2,8 +2,9 @@
 
 A filter "tensor" of the reference (a TF resource handle) is a HashFilter object here."""
 import ctypes as C
-from typing import List, Optional
+from typing import List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from monolith_amd import _lib
@@ -31,6 +32,7 @@ class HashFilter:
     thr = (C.c_int32 * max(n, 1))(*list(st.values()))
     self.kind = kind
     self.name = name
+    self.split_num = int(split_num)  # as given: SlidingHashFilter::split_num_ is the unclamped value
     self._h = C.c_void_p()
     _lib.check(_lib.lib.mono_filter_create(
         C.c_int(1 if kind == "sliding" else 0), C.c_int64(capacity), C.c_int(split_num),
@@ -72,6 +74,84 @@ class HashFilter:
     return {"head": int(buf[0]), "head_increment": int(buf[1]), "failure_count": int(buf[2]),
             "n_blocks": nb, "block_total_size": int(buf[4]),
             "num_elements": [int(buf[5 + i]) for i in range(nb)]}
+
+
+def save_hash_filter(hash_filter: HashFilter, hash_filter_basename: str,
+                     enable_hash_filter: bool = False) -> None:
+  """hash_filter_ops.py:140-147 -> MonolithHashFilterSave (ops/hash_filter_save_op.cc:41-105):
+  one file per block, <basename>-%05d-of-<split_num>; a dummy filter has no splits and writes
+  nothing."""
+  if enable_hash_filter is not True or hash_filter.kind != "sliding":
+    return
+  from monolith_amd import checkpoint
+  st = hash_filter.state()
+  nb, n_cells = st["n_blocks"], st["block_total_size"] + 64
+  sliding = {"split_num": hash_filter.split_num, "max_forward_step": 2,
+             "max_backward_step": nb - 2, "max_step": 16, "head": st["head"],
+             "head_increment": st["head_increment"], "failure_count": st["failure_count"]}
+  cells = np.empty(n_cells, np.uint16)
+  for b in range(nb):
+    ne = C.c_int64()
+    _lib.check(_lib.lib.mono_filter_export_split(
+        hash_filter.handle, C.c_int(b), C.c_void_p(cells.ctypes.data), C.c_int64(n_cells),
+        C.byref(ne), _lib.stream_ptr()))
+    meta = {"failure_count": 0, "total_size": st["block_total_size"], "num_elements": ne.value,
+            "fill_rate": 1.2, "sliding": sliding}
+    checkpoint.write_filter_split(checkpoint.sharded_name(str(hash_filter_basename), b, nb), meta,
+                                  cells)
+
+
+def restore_hash_filter(hash_filter: HashFilter, hash_filter_base_name: str,
+                        enable_hash_filter: bool = False) -> None:
+  """hash_filter_ops.py:150-157 -> MonolithHashFilterRestore (ops/hash_filter_restore_op.cc:36-110,
+  sliding_hash_filter.cc:187-213): split_num / max_forward_step / max_backward_step / max_step of
+  the dump must match the filter, head / head_increment / failure_count are taken from it."""
+  if enable_hash_filter is not True:
+    return
+  from monolith_amd import checkpoint
+  files = checkpoint.filter_files(str(hash_filter_base_name))
+  if hash_filter.kind != "sliding":
+    raise _lib.MonolithHipError("restore_hash_filter: dump files for a filter without splits")
+  st = hash_filter.state()
+  nb, n_cells = st["n_blocks"], st["block_total_size"] + 64
+  if len(files) != nb:
+    raise ValueError("split_num: %d does't match with : %d read from hash filter checkpoint file."
+                     % (nb, len(files)))
+  expect = {"split_num": hash_filter.split_num, "max_forward_step": 2, "max_backward_step": nb - 2,
+            "max_step": 16}
+  last = None
+  for b, f in enumerate(files):
+    meta, cells = checkpoint.read_filter_split(f)
+    for k, v in expect.items():
+      if meta["sliding"][k] != v:
+        raise ValueError("%s: %d does't match with : %d read from hash filter checkpoint file."
+                         % (k, v, meta["sliding"][k]))
+    if len(cells) != n_cells:
+      raise ValueError("total_size: %d does't match with : %d read from hash filter checkpoint "
+                       "file." % (st["block_total_size"], meta["total_size"]))
+    cells = np.ascontiguousarray(cells)
+    _lib.check(_lib.lib.mono_filter_import_split(
+        hash_filter.handle, C.c_int(b), C.c_void_p(cells.ctypes.data), C.c_int64(n_cells),
+        C.c_int64(meta["num_elements"]), _lib.stream_ptr()))
+    last = meta["sliding"]
+  _lib.check(_lib.lib.mono_filter_set_state(
+      hash_filter.handle, C.c_int64(last["head"]), C.c_int64(last["head_increment"]),
+      C.c_int64(last["failure_count"]), _lib.stream_ptr()))
+
+
+def save_hash_filters(asset_dir: str, hash_filters: Sequence[HashFilter],
+                      enable_hash_filter: bool = False) -> None:
+  """HashFilterCheckpointSaverListener.before_save (hash_filter_ops.py:203-226):
+  <asset_dir>hash_filter_<ps index>."""
+  for ps_idx, f in enumerate(hash_filters):
+    save_hash_filter(f, asset_dir + "hash_filter_{}".format(ps_idx), enable_hash_filter)
+
+
+def restore_hash_filters(asset_dir: str, hash_filters: Sequence[HashFilter],
+                         enable_hash_filter: bool = False) -> None:
+  """HashFilterCheckpointRestorerListener._restore_from_path_prefix (hash_filter_ops.py:287-303)."""
+  for ps_idx, f in enumerate(hash_filters):
+    restore_hash_filter(f, asset_dir + "hash_filter_{}".format(ps_idx), enable_hash_filter)
 
 
 def create_hash_filter(capacity: int, split_num: int,

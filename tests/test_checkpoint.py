@@ -249,3 +249,132 @@ def test_checkpoint_dir_helpers_and_extra_restore_names(tmp_path):
   t3 = ops.test_hash_table(1, name_suffix="never_saved")
   with pytest.raises(ValueError):
     ops.restore_hash_tables(asset_dir, [t3])
+
+
+# ----------------------------------------------------------------------------- hash-filter dumps
+def test_filter_dump_messages_roundtrip_and_known_bytes():
+  """HashFilterSplitMetaDump / HashFilterSplitDataDump wire format
+  (embedding_hash_table.proto:108-133). No dump file of a filter ships with the reference, so the
+  bytes are pinned to the proto definition only ("parity unpinned" against a reference-written
+  file): hand-assembled messages, plus python-protobuf's own encoder when it is importable."""
+  sliding = {"split_num": 7, "max_forward_step": 2, "max_backward_step": 5, "max_step": 16,
+             "head": 3, "head_increment": 300, "failure_count": 0}
+  meta = {"failure_count": 0, "total_size": 60, "num_elements": 2, "fill_rate": 1.2,
+          "sliding": sliding}
+  b = ck.encode_filter_meta(meta)
+  import struct
+  sl = bytes([0x08, 7, 0x10, 2, 0x18, 5, 0x20, 16, 0x28, 3, 0x30, 0xAC, 0x02, 0x38, 0])
+  assert b == bytes([0x08, 0, 0x10, 60, 0x18, 2, 0x21]) + struct.pack("<d", 1.2) + \
+      bytes([0x2A, len(sl)]) + sl
+  assert ck.decode_filter_meta(b) == meta
+  cells = np.array([0, 1, 127, 128, 0x3FFF, 0x4000, 0xFFFF, (0xABC << 4) | 3], np.uint16)
+  d = ck.encode_filter_data(20000, cells)
+  assert d == bytes([0x08, 0xA0, 0x9C, 0x01, 0x10, 0, 0x10, 1, 0x10, 127, 0x10, 0x80, 0x01,
+                     0x10, 0xFF, 0x7F, 0x10, 0x80, 0x80, 0x01, 0x10, 0xFF, 0xFF, 0x03,
+                     0x10, 0xC3, 0xD7, 0x02])
+  off, back = ck.decode_filter_data(d)
+  assert off == 20000 and np.array_equal(back, cells)
+  # a packed encoding of the same message parses too (generic path)
+  packed = bytes([0x08, 5, 0x12, 3, 1, 0x80, 0x01])
+  assert ck.decode_filter_data(packed)[0] == 5
+  assert ck.decode_filter_data(packed)[1].tolist() == [1, 128]
+  rng = np.random.Generator(np.random.PCG64(1))
+  big = rng.integers(0, 65536, 10000).astype(np.uint16)
+  off, back = ck.decode_filter_data(ck.encode_filter_data(0, big))
+  assert off == 0 and np.array_equal(back, big)
+
+
+def test_filter_split_file_roundtrip(tmp_path):
+  """One block file: meta record + ceil(cells / 10000) data records (hash_filter.cc:25-56)."""
+  rng = np.random.Generator(np.random.PCG64(2))
+  cells = np.where(rng.random(25064) < 0.3, rng.integers(1, 65536, 25064), 0).astype(np.uint16)
+  meta = {"failure_count": 0, "total_size": 25000, "num_elements": 7000, "fill_rate": 1.2,
+          "sliding": {"split_num": 7, "max_forward_step": 2, "max_backward_step": 5, "max_step": 16,
+                      "head": 6, "head_increment": 13, "failure_count": 4}}
+  p = str(tmp_path / "d" / "hash_filter_0-00003-of-00007")
+  ck.write_filter_split(p, meta, cells)
+  buf, off, ln = ck.read_records(p)
+  assert len(off) == 1 + 3
+  m2, c2 = ck.read_filter_split(p)
+  assert m2 == meta and np.array_equal(c2, cells)
+
+
+@pytest.mark.gpu
+def test_hash_filter_save_restore(tmp_path):
+  """hash_filter_ops_test.py:60-103: threshold 3, ids [1, 3 << 17, 1]; save / restore in the
+  middle of the sequence leaves the pass pattern of the four runs unchanged, 7 files per dump."""
+  import torch
+  from monolith_amd import hash_filter_ops as ops
+  cfg = entry.SlotOccurrenceThresholdConfig(default_occurrence_threshold=3)
+  f = ops.create_hash_filter(100, 7, cfg)
+  ids = _ids_t([1, 3 << 17, 1])
+
+  def run():
+    emb = torch.zeros(3, 2, device="cuda:0", requires_grad=True)
+    ops.intercept_gradient(f, ids, emb).sum().backward()
+    return emb.grad.cpu().tolist()
+
+  base0 = str(tmp_path / "f" / "hash_filter_test_0")
+  ops.save_hash_filter(f, base0, True)
+  assert len(glob.glob(base0 + "*")) == 7
+  ops.restore_hash_filter(f, base0, True)
+  assert run() == [[0, 0], [0, 0], [0, 0]]
+  assert run() == [[0, 0], [0, 0], [1, 1]]
+  base1 = str(tmp_path / "f" / "hash_filter_test_1")
+  ops.save_hash_filter(f, base1, True)
+  assert len(glob.glob(base1 + "*")) == 7
+  # counts move on, then the restore brings checkpoint 1 back
+  run()
+  ops.restore_hash_filter(f, base1, True)
+  assert run() == [[1, 1], [0, 0], [1, 1]]
+  assert run() == [[1, 1], [1, 1], [1, 1]]
+  # into a fresh filter of the same shape: same continuation
+  g = ops.create_hash_filter(100, 7, cfg)
+  ops.restore_hash_filter(g, base1, True)
+  ops.restore_hash_filter(f, base1, True)
+  assert g.get(_ids_t([1, 3 << 17, 5])).cpu().tolist() == [4, 2, 0]
+  assert f.get(_ids_t([1, 3 << 17, 5])).cpu().tolist() == [4, 2, 0]
+  # shape mismatch is rejected like SlidingHashFilter::ValidateData
+  with pytest.raises(ValueError):
+    ops.restore_hash_filter(ops.create_hash_filter(100, 9, cfg), base1, True)
+  # enable_hash_filter False: no-op both ways
+  ops.save_hash_filter(f, str(tmp_path / "none" / "x"), False)
+  assert not os.path.exists(str(tmp_path / "none"))
+  ops.restore_hash_filter(f, str(tmp_path / "none" / "x"), False)
+
+
+@pytest.mark.gpu
+def test_hash_filter_dump_carries_rotation_state(tmp_path):
+  """hash_filter_ops_test.py:105-177 shape (capacity 300, 100 splits -> blocks of total_size 3):
+  ids fed one per call so rotation falls where the reference puts it; after two passes the dump's
+  meta shows head = head_increment = 4 and num_elements 2 in the first four blocks, and a
+  restored filter continues identically."""
+  import torch
+  from monolith_amd import hash_filter_ops as ops
+  cfg = entry.SlotOccurrenceThresholdConfig(default_occurrence_threshold=2)
+  f = ops.create_hash_filter(300, 100, cfg)
+  base0 = str(tmp_path / "hash_filter_test_0")
+  ops.save_hash_filter(f, base0, True)
+  files = sorted(glob.glob(base0 + "*"))
+  assert len(files) == 100
+  for p in files:
+    m, cells = ck.read_filter_split(p)
+    assert m["total_size"] == 3 and m["num_elements"] == 0 and len(cells) == 67
+    assert m["sliding"]["split_num"] == 100 and m["sliding"]["head"] == 0
+    assert m["sliding"]["head_increment"] == 0
+  seq = [1, 1 << 17, 2 << 17, 1]
+  one = torch.ones(1, dtype=torch.int32, device="cuda:0")
+  old = [[int(f.add(_ids_t([i]), one)[0]) for i in seq] for _ in range(2)]
+  assert old == [[0, 0, 0, 1], [2, 1, 1, 3]]
+  base1 = str(tmp_path / "hash_filter_test_1")
+  ops.save_hash_filter(f, base1, True)
+  files = sorted(glob.glob(base1 + "*"))
+  for k, p in enumerate(files):
+    m, _ = ck.read_filter_split(p)
+    assert m["num_elements"] == (2 if k < 4 else 0)
+    assert m["sliding"]["head"] == 4 and m["sliding"]["head_increment"] == 4
+  g = ops.create_hash_filter(300, 100, cfg)
+  ops.restore_hash_filter(g, base1, True)
+  assert g.state() == f.state()
+  assert [int(g.add(_ids_t([i]), one)[0]) for i in seq] == \
+      [int(f.add(_ids_t([i]), one)[0]) for i in seq]
