@@ -1,0 +1,139 @@
+"""Cross-check of the hand-written wire encoders / parsers in monolith_amd/checkpoint.py against
+the protobuf runtime. The message definitions are restated from the reference's .proto files
+(runtime/hash_table/embedding_hash_table.proto:45-50,108-133, optimizer/optimizer.proto:28-30,
+56-57,69-72,216-236) as dynamic descriptors — nothing is generated or copied from the reference."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pb = pytest.importorskip("google.protobuf")
+from google.protobuf import descriptor_pb2, descriptor_pool, message_factory  # noqa: E402
+
+from monolith_amd import checkpoint as ck  # noqa: E402
+
+F = descriptor_pb2.FieldDescriptorProto
+CKPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt")
+
+
+def _msg(fd, name, fields):
+  m = fd.message_type.add()
+  m.name = name
+  for fname, num, ftype, label, tname in fields:
+    f = m.field.add()
+    f.name, f.number, f.type, f.label = fname, num, ftype, label
+    if tname:
+      f.type_name = ".t." + tname
+  return m
+
+
+@pytest.fixture(scope="module")
+def classes():
+  fd = descriptor_pb2.FileDescriptorProto()
+  fd.name, fd.package, fd.syntax = "mono_ckpt_test.proto", "t", "proto2"
+  O, R = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+  _msg(fd, "AdagradOptimizerDump", [("norm", 1, F.TYPE_FLOAT, R, None)])
+  _msg(fd, "SgdOptimizerDump", [])
+  _msg(fd, "FtrlOptimizerDump", [("zero", 1, F.TYPE_FLOAT, R, None),
+                                 ("norm", 2, F.TYPE_FLOAT, R, None)])
+  _msg(fd, "SingleOptimizerDump", [("adagrad", 1, F.TYPE_MESSAGE, O, "AdagradOptimizerDump"),
+                                   ("sgd", 2, F.TYPE_MESSAGE, O, "SgdOptimizerDump"),
+                                   ("ftrl", 3, F.TYPE_MESSAGE, O, "FtrlOptimizerDump")])
+  _msg(fd, "OptimizerDump", [("dump", 1, F.TYPE_MESSAGE, R, "SingleOptimizerDump")])
+  _msg(fd, "EntryDump", [("id", 1, F.TYPE_SFIXED64, O, None), ("num", 2, F.TYPE_FLOAT, R, None),
+                         ("opt", 3, F.TYPE_MESSAGE, O, "OptimizerDump"),
+                         ("last_update_ts_sec", 4, F.TYPE_INT64, O, None)])
+  _msg(fd, "SlidingHashFilterMetaDump",
+       [(n, i + 1, F.TYPE_UINT64 if n == "failure_count" else F.TYPE_UINT32, O, None)
+        for i, n in enumerate(["split_num", "max_forward_step", "max_backward_step", "max_step",
+                               "head", "head_increment", "failure_count"])])
+  _msg(fd, "HashFilterSplitMetaDump",
+       [("failure_count", 1, F.TYPE_UINT64, O, None), ("total_size", 2, F.TYPE_UINT64, O, None),
+        ("num_elements", 3, F.TYPE_UINT64, O, None), ("fill_rate", 4, F.TYPE_DOUBLE, O, None),
+        ("sliding_hash_filter_meta", 5, F.TYPE_MESSAGE, O, "SlidingHashFilterMetaDump")])
+  _msg(fd, "HashFilterSplitDataDump", [("offset", 1, F.TYPE_UINT32, O, None),
+                                       ("data", 2, F.TYPE_UINT32, R, None)])
+  pool = descriptor_pool.DescriptorPool()
+  pool.Add(fd)
+  return {n: message_factory.GetMessageClass(pool.FindMessageTypeByName("t." + n))
+          for n in ("EntryDump", "HashFilterSplitMetaDump", "HashFilterSplitDataDump")}
+
+
+def _entry_msg(cls, layout, rid, row, ts):
+  m = cls["EntryDump"]()
+  m.id = int(rid)
+  m.num.extend(float(x) for x in row[:layout.dim])
+  cur = layout.dim
+  m.opt.SetInParent()
+  for d, kind in layout.segments:
+    s = m.opt.dump.add()
+    if kind == ck.ADAGRAD:
+      s.adagrad.norm.extend(float(x) for x in row[cur:cur + d])
+      cur += d
+    elif kind == ck.FTRL:  # row state order norm | zero (ftrl_optimizer.cc:38-45)
+      s.ftrl.zero.extend(float(x) for x in row[cur + d:cur + 2 * d])
+      s.ftrl.norm.extend(float(x) for x in row[cur:cur + d])
+      cur += 2 * d
+    else:
+      s.sgd.SetInParent()
+  m.last_update_ts_sec = int(ts)
+  return m
+
+
+def test_entry_dump_encoder_equals_protobuf(classes):
+  layout = ck.DumpLayout([(3, ck.ADAGRAD), (2, ck.FTRL), (4, ck.SGD), (1, ck.ADAGRAD)])
+  rng = np.random.Generator(np.random.PCG64(11))
+  n = 64
+  ids = rng.integers(-2**62, 2**62, n)
+  rows = rng.normal(0, 1, (n, layout.row_floats)).astype(np.float32)
+  ts = rng.choice([0, 1, 127, 128, 1 << 20, 1_700_000_000, 2**32 - 1], n).astype(np.uint32)
+  mine = {}
+  for grp in layout.encode(ids, rows, ts):
+    for rec in grp:
+      m = classes["EntryDump"]()
+      m.ParseFromString(rec.tobytes())
+      mine[m.id] = rec.tobytes()
+  assert len(mine) == n
+  for i in range(n):
+    assert _entry_msg(classes, layout, ids[i], rows[i], ts[i]).SerializeToString() == mine[int(ids[i])]
+
+
+def test_reference_dumps_parse_identically_with_protobuf(classes):
+  from tests.test_checkpoint import TABLES
+  seen = 0
+  for f in sorted(glob.glob(os.path.join(CKPT, "MonolithHashTable_*"))):
+    buf, off, ln = ck.read_records(f)
+    if not len(off):
+      continue
+    layout = ck.DumpLayout(TABLES[os.path.basename(f).split("_")[1].split("-")[0]])
+    ids, rows, ts = layout.decode(buf, off, ln)
+    for i in range(len(off)):
+      raw = buf[off[i]:off[i] + ln[i]].tobytes()
+      m = classes["EntryDump"]()
+      m.ParseFromString(raw)
+      assert m.id == ids[i] and m.last_update_ts_sec == ts[i]
+      assert _entry_msg(classes, layout, ids[i], rows[i], ts[i]).SerializeToString() == raw
+      seen += 1
+  assert seen == 30
+
+
+def test_filter_messages_equal_protobuf(classes):
+  sliding = {"split_num": 100, "max_forward_step": 2, "max_backward_step": 98, "max_step": 16,
+             "head": 4, "head_increment": 70000, "failure_count": 1 << 40}
+  meta = {"failure_count": 0, "total_size": 51428571, "num_elements": 123456, "fill_rate": 1.2,
+          "sliding": sliding}
+  m = classes["HashFilterSplitMetaDump"]()
+  m.failure_count, m.total_size, m.num_elements, m.fill_rate = 0, 51428571, 123456, 1.2
+  for k, v in sliding.items():
+    setattr(m.sliding_hash_filter_meta, k, v)
+  assert m.SerializeToString() == ck.encode_filter_meta(meta)
+  assert ck.decode_filter_meta(m.SerializeToString()) == meta
+  rng = np.random.Generator(np.random.PCG64(5))
+  cells = rng.integers(0, 65536, 3000).astype(np.uint16)
+  d = classes["HashFilterSplitDataDump"]()
+  d.offset = 30000
+  d.data.extend(int(x) for x in cells)
+  assert d.SerializeToString() == ck.encode_filter_data(30000, cells)
+  off, back = ck.decode_filter_data(d.SerializeToString())
+  assert off == 30000 and np.array_equal(back, cells)
