@@ -168,6 +168,22 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
                                   int64_t* h_n_unique, int32_t* h_shard_sizes,
                                   int32_t* h_sharded_slot_sizes, int32_t* const* out_offsets,
                                   void* stream);
+/* ShardingSparseFidsV2 on device-resident ragged FIDs: data/kernels/parse_sparse_feature.cc:173-211
+ * (FillFidList: shard = uint64(fid) % ps_num), :213-288 (CreateOffsetTensor),
+ * parse_sparse_feature.h:1472-1680 (FeatureParallelUniqueParse), data/parsers.py:402-456.
+ * Protobuf parsing is NOT part of this entry point: fids[m] / row_splits[m] are the M configured
+ * features in sorted-name order, row_splits[m] = int64[h_runs[m] + 1] relative to fids[m]
+ * (h_runs[m] = batch, 1 for a feature shared by the batch, 0 for a feature absent from the input).
+ * h_out_index[m * ps_num + shard] = FeatureInfo::GetFidOutputIndex (parse_sparse_feature.h:135-142),
+ * all < n_out. Outputs: out_fid_list = the FIDs grouped by out index (ascending), each group in
+ * first-occurrence order (unique) or input order; h_out_counts[n_out] = group sizes (host);
+ * out_fid_offset[k] = (out index << 32) | index of FID k inside its group; out_feature_offset[j] =
+ * first FID position of run j. Synchronises the stream. */
+int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* row_splits,
+                              const int64_t* h_lens, const int64_t* h_runs, int M, int ps_num,
+                              const int32_t* h_out_index, int n_out, int unique,
+                              int64_t* out_fid_list, uint64_t* out_fid_offset,
+                              int32_t* out_feature_offset, int32_t* h_out_counts, void* stream);
 /* ops/map_id_to_embedding_op.cc:239-292 / map_id_to_embedding.cu.cc:30-74. */
 int mono_fused_gather_embeddings_by_input(const float* fused, int64_t fused_len,
                                           const int32_t* const* offsets, const int64_t* h_lens,

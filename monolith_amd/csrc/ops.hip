@@ -368,6 +368,97 @@ __global__ void __launch_bounds__(256) k_reorder_offsets(ReorderArgs a, const Sl
   }
 }
 
+// ------------------------------------------------------------- sharding_sparse_fids (8f-2)
+// data/kernels/parse_sparse_feature.cc:173-211 (FillFidList) + parse_sparse_feature.h:1472-1680
+// (FeatureParallelUniqueParse) on ragged FID arrays that are already on the device.
+struct ShardArgs {
+  int M, ps_num, n_out, unique;
+  int64_t total;
+  const int32_t* out_index;  // [M * ps_num] GetFidOutputIndex(feature m, shard)
+};
+
+__device__ __forceinline__ int shard_of_fid(int64_t id, int ps_num) {  // unsigned % (:178, :195)
+  return (int)((uint64_t)id % (uint64_t)ps_num);
+}
+
+__global__ void __launch_bounds__(256) k_shard_keys(ShardArgs a, const SlotMeta* sm,
+                                                    const uint32_t* hfirst, const uint32_t* hcell,
+                                                    uint32_t* skey) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const int m = find_slot_of(sm, a.M, g);
+    uint32_t key = (uint32_t)a.n_out;
+    if (!a.unique || hfirst[hcell[g]] == (uint32_t)g) {
+      const int64_t id = sm[m].ids[g - sm[m].base];
+      key = (uint32_t)a.out_index[m * a.ps_num + shard_of_fid(id, a.ps_num)];
+    }
+    skey[g] = key;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_shard_hist(ShardArgs a, const uint32_t* skey,
+                                                    int32_t* hist) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < a.n_out; c += gridDim.x * blockDim.x)
+    hist[c] = (int32_t)(lower_bound_dev(skey, a.total, (int64_t)c + 1) -
+                        lower_bound_dev(skey, a.total, (int64_t)c));
+}
+
+// sorted position r -> fid_list[r] and the index of the fid inside its (feature, shard) list
+__global__ void __launch_bounds__(256) k_shard_emit(ShardArgs a, const SlotMeta* sm,
+                                                    const uint32_t* skey, const uint32_t* sidx,
+                                                    const int32_t* start, const uint32_t* hcell,
+                                                    uint32_t* hfirst, int64_t* fid_list,
+                                                    uint64_t* fid_offset) {
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.total;
+       r += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t key = skey[r];
+    if (key >= (uint32_t)a.n_out) continue;
+    const uint32_t g = sidx[r];
+    const int m = find_slot_of(sm, a.M, g);
+    fid_list[r] = sm[m].ids[(int64_t)g - sm[m].base];
+    const uint32_t idx = (uint32_t)(r - start[key]);
+    if (a.unique) hfirst[hcell[g]] = idx;  // the dedup cell now carries the list index
+    else fid_offset[g] = ((uint64_t)key << 32) | idx;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_shard_offsets(ShardArgs a, const SlotMeta* sm,
+                                                       const uint32_t* hfirst,
+                                                       const uint32_t* hcell,
+                                                       uint64_t* fid_offset) {
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total;
+       g += (int64_t)gridDim.x * blockDim.x) {
+    const int m = find_slot_of(sm, a.M, g);
+    const int64_t id = sm[m].ids[g - sm[m].base];
+    const uint32_t key = (uint32_t)a.out_index[m * a.ps_num + shard_of_fid(id, a.ps_num)];
+    fid_offset[g] = ((uint64_t)key << 32) | hfirst[hcell[g]];
+  }
+}
+
+struct RunMeta {  // per feature: its run boundaries -> feature_offset entries
+  const int64_t* row_splits;  // [runs + 1], relative to the feature's first fid
+  int64_t fid_base;           // first global fid position of the feature
+  int64_t run_base;           // first feature_offset entry of the feature
+  int64_t runs;
+};
+
+__global__ void __launch_bounds__(256) k_shard_feature_offsets(const RunMeta* rm, int M,
+                                                               int64_t total_runs,
+                                                               int32_t* feature_offset) {
+  for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < total_runs;
+       j += (int64_t)gridDim.x * blockDim.x) {
+    int lo = 0, hi = M - 1;
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (rm[mid].run_base <= j) lo = mid; else hi = mid - 1;
+    }
+    // features without runs share a run_base with their successor: take the one that owns j
+    while (lo > 0 && rm[lo].runs == 0) --lo;
+    const RunMeta r = rm[lo];
+    feature_offset[j] = (int32_t)(r.fid_base + r.row_splits[j - r.run_base]);
+  }
+}
+
 static SplitArgs single_split(float* out, int64_t dim) {
   SplitArgs sp{};
   sp.M = 1;
@@ -632,6 +723,103 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
       uniq += h_sharded_slot_sizes[n * M + m];
     }
   *h_n_unique = uniq;
+  return 0;
+}
+
+int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* row_splits,
+                              const int64_t* h_lens, const int64_t* h_runs, int M, int ps_num,
+                              const int32_t* h_out_index, int n_out, int unique,
+                              int64_t* out_fid_list, uint64_t* out_fid_offset,
+                              int32_t* out_feature_offset, int32_t* h_out_counts, void* stream) {
+  MONO_REQUIRE(M >= 1 && ps_num >= 1 && n_out >= 1, "mono_sharding_sparse_fids: M %d ps_num %d n_out %d",
+               M, ps_num, n_out);
+  MONO_REQUIRE(h_lens && h_runs && h_out_index && h_out_counts, "mono_sharding_sparse_fids: null argument");
+  for (int i = 0; i < M * ps_num; ++i)
+    MONO_REQUIRE(h_out_index[i] >= 0 && h_out_index[i] < n_out,
+                 "mono_sharding_sparse_fids: out_index[%d] = %d outside [0, %d)", i, h_out_index[i], n_out);
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < n_out; ++i) h_out_counts[i] = 0;
+  std::vector<SlotMeta> sm(M);
+  std::vector<RunMeta> rm(M);
+  int64_t total = 0, cells = 0, total_runs = 0;
+  for (int m = 0; m < M; ++m) {
+    MONO_REQUIRE(h_lens[m] >= 0 && h_runs[m] >= 0, "mono_sharding_sparse_fids: negative length");
+    MONO_REQUIRE(h_lens[m] == 0 || fids[m], "mono_sharding_sparse_fids: null fids[%d]", m);
+    MONO_REQUIRE(h_runs[m] == 0 || row_splits[m], "mono_sharding_sparse_fids: null row_splits[%d]", m);
+    MONO_REQUIRE(h_runs[m] > 0 || h_lens[m] == 0, "mono_sharding_sparse_fids: fids without runs");
+    uint64_t sz = 8;
+    while (sz < (uint64_t)h_lens[m] * 2) sz <<= 1;
+    sm[m] = SlotMeta{fids[m], nullptr, total, h_lens[m], cells, sz - 1, 1};
+    rm[m] = RunMeta{row_splits[m], total, total_runs, h_runs[m]};
+    total += h_lens[m];
+    total_runs += h_runs[m];
+    if (unique) cells += (int64_t)sz + 1;
+  }
+  MONO_REQUIRE(total < (int64_t)0x7FFFFFF0ll && cells < (int64_t)0xFFFFFFF0ll &&
+               total_runs < (int64_t)0x7FFFFFF0ll, "mono_sharding_sparse_fids: too many ids");
+  MONO_REQUIRE(total_runs == 0 || out_feature_offset, "mono_sharding_sparse_fids: null feature_offset");
+  MONO_REQUIRE(total == 0 || (out_fid_list && out_fid_offset), "mono_sharding_sparse_fids: null output");
+  const size_t t_al = ((size_t)total + 63) & ~(size_t)63;
+  const size_t c_al = ((size_t)cells + 63) & ~(size_t)63;
+  const size_t o_al = ((size_t)(n_out + 1) + 63) & ~(size_t)63;
+  const size_t off_sm = 256;
+  const size_t off_rm = (off_sm + sizeof(SlotMeta) * M + 63) & ~(size_t)63;
+  const size_t off_oi = (off_rm + sizeof(RunMeta) * M + 63) & ~(size_t)63;
+  const size_t off_hkeys = (off_oi + (size_t)M * ps_num * 4 + 63) & ~(size_t)63;
+  const size_t off_hfirst = off_hkeys + c_al * 8;
+  const size_t off_hcell = off_hfirst + c_al * 4;
+  const size_t off_skey = off_hcell + (unique ? t_al * 4 : 0);
+  const size_t off_skey2 = off_skey + t_al * 4;
+  const size_t off_sidx2 = off_skey2 + t_al * 4;
+  const size_t off_hist = off_sidx2 + t_al * 4;
+  const size_t off_start = off_hist + o_al * 4;
+  MONO_TRY(g_ws.ensure(off_start + o_al * 4));
+  char* base = (char*)g_ws.ptr;
+  SlotMeta* d_sm = (SlotMeta*)(base + off_sm);
+  RunMeta* d_rm = (RunMeta*)(base + off_rm);
+  int32_t* d_oi = (int32_t*)(base + off_oi);
+  int64_t* hkeys = (int64_t*)(base + off_hkeys);
+  uint32_t* hfirst = (uint32_t*)(base + off_hfirst);
+  uint32_t* hcell = (uint32_t*)(base + off_hcell);
+  uint32_t* skey = (uint32_t*)(base + off_skey);
+  uint32_t* skey2 = (uint32_t*)(base + off_skey2);
+  uint32_t* sidx2 = (uint32_t*)(base + off_sidx2);
+  int32_t* hist = (int32_t*)(base + off_hist);
+  int32_t* start = (int32_t*)(base + off_start);
+  MONO_HIP(hipMemcpyAsync(d_sm, sm.data(), sizeof(SlotMeta) * M, hipMemcpyHostToDevice, st));
+  MONO_HIP(hipMemcpyAsync(d_rm, rm.data(), sizeof(RunMeta) * M, hipMemcpyHostToDevice, st));
+  MONO_HIP(hipMemcpyAsync(d_oi, h_out_index, (size_t)M * ps_num * 4, hipMemcpyHostToDevice, st));
+  const dim3 blk(256);
+  if (total_runs > 0)
+    hipLaunchKernelGGL(k_shard_feature_offsets, dim3(grid_for(total_runs, 256)), blk, 0, st, d_rm, M,
+                       total_runs, out_feature_offset);
+  if (total == 0) {
+    MONO_HIP(hipGetLastError());
+    MONO_HIP(hipStreamSynchronize(st));  // sm / rm / h_out_index are read by the copies above
+    return 0;
+  }
+  const dim3 grid(grid_for(total, 256));
+  ShardArgs a{M, ps_num, n_out, unique ? 1 : 0, total, d_oi};
+  if (unique) {
+    MONO_HIP(hipMemsetAsync(hkeys, 0xFF, c_al * 8, st));
+    MONO_HIP(hipMemsetAsync(hfirst, 0xFF, c_al * 4, st));
+    ReorderArgs ra{M, ps_num, 0, total};
+    hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hkeys, hfirst, hcell, 0);
+    hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hkeys, hfirst, hcell, 1);
+  }
+  hipLaunchKernelGGL(k_shard_keys, grid, blk, 0, st, a, d_sm, hfirst, hcell, skey);
+  MONO_HIP(hipGetLastError());
+  MONO_TRY(sort_pairs(skey, skey2, nullptr, sidx2, (size_t)total, bits_for_u((uint64_t)n_out), st));
+  hipLaunchKernelGGL(k_shard_hist, dim3(grid_for(n_out, 256)), blk, 0, st, a, skey2, hist);
+  MONO_HIP(hipGetLastError());
+  MONO_TRY(exclusive_scan_i32(hist, start, (size_t)n_out, st));
+  hipLaunchKernelGGL(k_shard_emit, grid, blk, 0, st, a, d_sm, skey2, sidx2, start, hcell, hfirst,
+                     out_fid_list, out_fid_offset);
+  if (unique)
+    hipLaunchKernelGGL(k_shard_offsets, grid, blk, 0, st, a, d_sm, hfirst, hcell, out_fid_offset);
+  MONO_HIP(hipGetLastError());
+  MONO_HIP(hipMemcpyAsync(h_out_counts, hist, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipStreamSynchronize(st));
   return 0;
 }
 

@@ -443,3 +443,63 @@ def bench_lookup_apply_mt(segments, ids_batches, grads, lr, threads):
           int(threads), C.byref(rows))
   del keep
   return float(dt), int(rows.value)
+
+
+# ------------------------------------------------------------------ sharding_sparse_fids (8f-2)
+def sharding_sparse_fids(feature_tables, features, ps_num, unique):
+  """ShardingSparseFidsV2, sequential restatement (test infrastructure).
+
+  data/kernels/parse_sparse_feature.cc:92-141 (sorted tables / features, feature_in_table_index,
+  output_pre_index), :173-211 (FillFidList: shard = uint64 fid % ps_num; unique = hash map per
+  (feature, shard), index = first-occurrence rank), :213-288 (CreateOffsetTensor: nfl_offset with
+  bit 31 for shared features, feature_offset = running FID count per run),
+  parse_sparse_feature.h:1583-1636 (fid_list = features of a table back to back per ps,
+  fid_list_row_splits = prefix sums of the per-feature counts).
+
+  feature_tables: {feature name: table name} (every configured feature)
+  features: {feature name: ("shared", [fids]) | ("rows", [[fids] per sample])}; missing = absent
+  Returns (fid_list [table*ps_num+ps] int64 arrays, row_splits, fid_offset uint64, feature_offset
+  int32, nfl_offset uint32)."""
+  names = sorted(feature_tables)
+  tables = sorted(set(feature_tables.values()))
+  tfeat = {t: [n for n in names if feature_tables[n] == t] for t in tables}
+  pre, pre_index = {}, 0
+  for t in tables:
+    pre[t] = pre_index
+    pre_index += max(len(tfeat[t]), 1) * ps_num
+  lists = {(n, p): [] for n in names for p in range(ps_num)}
+  seen = {(n, p): {} for n in names for p in range(ps_num)}
+  fid_offset, feature_offset, nfl_offset = [], [], []
+  for n in names:
+    t = feature_tables[n]
+    nfl = len(feature_offset)
+    f = features.get(n)
+    if f is not None and f[0] == "shared":
+      nfl |= 1 << 31
+    nfl_offset.append(nfl)
+    if f is None:
+      continue
+    runs = [f[1]] if f[0] == "shared" else f[1]
+    for run in runs:
+      feature_offset.append(len(fid_offset))
+      for fid in run:
+        p = (int(fid) & 0xFFFFFFFFFFFFFFFF) % ps_num
+        out_index = pre[t] + p * len(tfeat[t]) + tfeat[t].index(n)
+        if unique:
+          idx = seen[(n, p)].get(fid)
+          if idx is None:
+            idx = len(lists[(n, p)])
+            seen[(n, p)][fid] = idx
+            lists[(n, p)].append(fid)
+        else:
+          idx = len(lists[(n, p)])
+          lists[(n, p)].append(fid)
+        fid_offset.append((out_index << 32) | idx)
+  fid_list, row_splits = [], []
+  for t in tables:
+    for p in range(ps_num):
+      parts = [lists[(n, p)] for n in tfeat[t]]
+      fid_list.append(np.array([x for part in parts for x in part], np.int64))
+      row_splits.append(np.cumsum([0] + [len(part) for part in parts]).astype(np.int64))
+  return (fid_list, row_splits, np.array(fid_offset, np.uint64),
+          np.array(feature_offset, np.int32), np.array(nfl_offset, np.uint32))
