@@ -20,6 +20,7 @@ reshape(sharded_slot_sizes, [N, K]) @ dims, :211-216).
 ..._gradient; it defaults to the HIP ops. (The CPU tests inject the oracle there to cover the
 exchange logic with gloo; the product path never does.)"""
 import copy
+import os
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -39,7 +40,10 @@ def alltoall(tensor: torch.Tensor, splits, recv_splits=None, group=None):
   `splits` / `recv_splits` are host int sequences (length world)."""
   rank, world = _world(group)
   splits = [int(x) for x in splits]
-  if world == 1:
+  if world == 1 and not (os.environ.get("MONOLITH_AMD_FORCE_COLLECTIVE") == "1" and
+                         dist.is_available() and dist.is_initialized()):
+    # (MONOLITH_AMD_FORCE_COLLECTIVE=1 sends even a one-rank exchange through the backend: the
+    # way to exercise the RCCL calls on a single-GPU box)
     return tensor, splits
   if tensor.is_cuda and dist.get_backend(group) == "gloo":
     # gloo has no device all-to-all: stage through the host (single-GPU rehearsals only; the

@@ -33,14 +33,18 @@ def _batch(rank, step):
   return ids, grads
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
   try:
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["MONOLITH_SYNC_EMPTY_RANK0_PS_SHARD"] = "1"  # N <= 4: plain floormod either way
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+      os.environ["MONOLITH_AMD_FORCE_COLLECTIVE"] = "1"
+      dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+      dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import cpu
     from monolith_amd import distributed_ps_sync, entry, hash_table_ops, multi_type_hash_table
 
@@ -119,3 +123,17 @@ def test_world2_exchange_on_hip_ops():
     p.join(timeout=30)
   for rank, err in res:
     assert err is None, "rank %d failed:\n%s" % (rank, err)
+
+
+def test_world1_exchange_over_rccl():
+  """The same step with backend "nccl" (= RCCL) at world size 1, the exchange forced through
+  dist.all_to_all_single (MONOLITH_AMD_FORCE_COLLECTIVE=1): device tensors, uneven split lists
+  and the int64 / fp32 payloads go through RCCL exactly as they do at N > 1 on a multi-GPU node
+  (which this pool's one-GPU box cannot host)."""
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q, "nccl"))
+  p.start()
+  rank, err = q.get(timeout=150)
+  p.join(timeout=30)
+  assert err is None, "rccl world-1 run failed:\n%s" % err
