@@ -75,6 +75,25 @@ def cpu_baseline(ids_batches, grad, lr):
                     "%d shard-owning threads" % (len(ids_np), len(ids_np[0]), rows, threads)}
 
 
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+  """Libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line there.
+  Everything else is sent to stderr, the JSON line goes to the saved descriptor."""
+  global _REAL_STDOUT
+  if _REAL_STDOUT is None:
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
+
+
+def emit(res):
+  line = (json.dumps(res) + "\n").encode()
+  sys.stdout.flush()
+  os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, line)
+
+
 def main_sharded(args, rank, world, device):
   """N > 1: DistributedMultiTypeHashTableMpi over one merged table sharded by floormod(fid, N)."""
   import torch.distributed as dist
@@ -184,8 +203,8 @@ def main_sharded(args, rank, world, device):
       "cpu_baseline": None,
   }
   if rank == 0:
-    print(json.dumps(res))
-  if world > 1:
+    emit(res)
+  if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
 
@@ -203,6 +222,7 @@ def main():
   ap.add_argument("--sharded", action="store_true",
                   help="run the N > 1 exchange pipeline even at N = 1 (profiling aid)")
   args = ap.parse_args()
+  quiet_stdout()
 
   rank = int(os.environ.get("RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -211,8 +231,13 @@ def main():
     local_rank = 0  # rehearsal: all ranks share the one GPU
   torch.cuda.set_device(local_rank)
   device = torch.device("cuda", local_rank)
-  if world > 1:
+  force = os.environ.get("MONOLITH_AMD_FORCE_COLLECTIVE") == "1"  # one-rank RCCL rehearsal
+  if world > 1 or force:
     import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
     if args.backend == "nccl":
       dist.init_process_group("nccl", device_id=device)
     else:
@@ -356,7 +381,7 @@ def main():
   elif rank == 0:
     res["cpu_baseline"] = None
   if rank == 0:
-    print(json.dumps(res))
+    emit(res)
   if world > 1:
     torch.distributed.destroy_process_group()
 
