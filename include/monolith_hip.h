@@ -27,7 +27,11 @@ extern "C" {
 /* ---- configuration PODs (mirror runtime/hash_table/embedding_hash_table.proto:19-87,
  *      optimizer/optimizer.proto:19-72, initializer/initializer_config.proto:19-46) ---- */
 
-enum { MONO_OPT_SGD = 0, MONO_OPT_ADAGRAD = 1, MONO_OPT_FTRL = 2 };
+enum {
+  MONO_OPT_SGD = 0, MONO_OPT_ADAGRAD = 1, MONO_OPT_FTRL = 2,
+  /* optimizer/{momentum,rmsprop,adadelta}_optimizer.cc */
+  MONO_OPT_MOMENTUM = 3, MONO_OPT_RMSPROP = 4, MONO_OPT_RMSPROP_V2 = 5, MONO_OPT_ADADELTA = 6
+};
 enum { MONO_INIT_ZEROS = 0, MONO_INIT_ONES = 1, MONO_INIT_CONSTANT = 2, MONO_INIT_UNIFORM = 3 };
 
 typedef struct {
@@ -41,6 +45,13 @@ typedef struct {
   int32_t init_kind;    /* MONO_INIT_* */
   float init_a;         /* constant value, or uniform minval */
   float init_b;         /* uniform maxval */
+  /* ABI version 2: */
+  float momentum;        /* Momentum / RMSProp(V2) momentum (0.9) */
+  float epsilon;         /* Adadelta epsilon (0.01) */
+  float averaging_ratio; /* Adadelta averaging_ratio (0.9) */
+  float learning_rate;   /* RMSProp reads the CONFIG learning rate (rmsprop_optimizer.cc:59), not
+                            the per-call tensor; default 0.01 */
+  int32_t use_nesterov;  /* Momentum */
 } mono_segment_cfg;
 
 typedef struct {

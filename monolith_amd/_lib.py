@@ -20,7 +20,9 @@ class SegCfg(C.Structure):  # mono_segment_cfg
   _fields_ = [("dim", C.c_int32), ("opt_kind", C.c_int32), ("init_acc", C.c_float),
               ("weight_decay", C.c_float), ("l1", C.c_float), ("l2", C.c_float),
               ("beta", C.c_float), ("init_kind", C.c_int32), ("init_a", C.c_float),
-              ("init_b", C.c_float)]
+              ("init_b", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float),
+              ("averaging_ratio", C.c_float), ("learning_rate", C.c_float),
+              ("use_nesterov", C.c_int32)]
 
 
 class TableCfg(C.Structure):  # mono_table_cfg

@@ -23,6 +23,19 @@ import numpy as np
 from monolith_amd import _lib, entry
 
 SGD, ADAGRAD, FTRL = entry.OPT_SGD, entry.OPT_ADAGRAD, entry.OPT_FTRL
+MOMENTUM, RMSPROP, RMSPROP_V2, ADADELTA = (entry.OPT_MOMENTUM, entry.OPT_RMSPROP,
+                                           entry.OPT_RMSPROP_V2, entry.OPT_ADADELTA)
+# SingleOptimizerDump oneof field (optimizer.proto:216-231) and, per optimizer, the dump's repeated
+# float fields in ROW order: [(field number, which state slot of the row)]
+_DUMP_FIELDS = {
+    SGD: (2, []),
+    ADAGRAD: (1, [(1, 0)]),            # norm
+    FTRL: (3, [(1, 1), (2, 0)]),       # zero = 1 <- slot 1, norm = 2 <- slot 0
+    ADADELTA: (6, [(1, 0), (2, 1)]),   # accum, accum_update
+    MOMENTUM: (9, [(1, 0)]),           # n
+    RMSPROP: (11, [(1, 0)]),           # n
+    RMSPROP_V2: (12, [(1, 0)]),        # n
+}
 
 
 def sharded_name(basename: str, idx: int, total: int) -> str:
@@ -93,9 +106,7 @@ def _read_varint(b, pos):
 
 
 def _opt_payload_len(kind: int, dim: int) -> int:
-  if kind == SGD:
-    return 0
-  return 5 * dim * (1 if kind == ADAGRAD else 2)
+  return 5 * dim * len(_DUMP_FIELDS[kind][1])
 
 
 def _len_prefixed(tag: int, n: int) -> bytes:
@@ -132,29 +143,16 @@ class DumpLayout:
     for d, k in self.segments:
       body = bytearray()
       marks = []
-      if k == ADAGRAD:
+      field, parts = _DUMP_FIELDS[k]
+      for fno, slot in parts:  # ascending field numbers = serialization order
         for i in range(d):
-          body += b"\x0d"
-          marks.append((len(body), st + i))
+          body.append((fno << 3) | 5)
+          marks.append((len(body), st + slot * d + i))
           body += b"\x00" * 4
-        st += d
-        single = _len_prefixed(0x0a, len(body)) + bytes(body)
-        hdr = len(_len_prefixed(0x0a, len(body)))
-      elif k == FTRL:  # row layout: norm[d] | zero[d]; dump: zero = 1, norm = 2
-        for i in range(d):
-          body += b"\x0d"
-          marks.append((len(body), st + d + i))
-          body += b"\x00" * 4
-        for i in range(d):
-          body += b"\x15"
-          marks.append((len(body), st + i))
-          body += b"\x00" * 4
-        st += 2 * d
-        single = _len_prefixed(0x1a, len(body)) + bytes(body)
-        hdr = len(_len_prefixed(0x1a, len(body)))
-      else:
-        single = b"\x12\x00"
-        hdr = 2
+      st += len(parts) * d
+      tag = (field << 3) | 2
+      single = _len_prefixed(tag, len(body)) + bytes(body)
+      hdr = len(_len_prefixed(tag, len(body)))
       singles.append((single, hdr, marks))
     opt = bytearray()
     opt_marks = []
@@ -324,20 +322,17 @@ class DumpLayout:
       n, p2 = _read_varint(single, p2) if single else (0, 0)
       body = single[p2:p2 + n]
       kind_field = tag >> 3
-      if k == ADAGRAD:
-        if kind_field != 1:
-          raise ValueError("segment expects an adagrad dump, found field %d" % kind_field)
-        row[st:st + d] = floats(body, [1])[1]
-        st += d
-      elif k == FTRL:
-        if kind_field != 3:
-          raise ValueError("segment expects an ftrl dump, found field %d" % kind_field)
-        r = floats(body, [1, 2])
-        row[st:st + d] = r[2]
-        row[st + d:st + 2 * d] = r[1]
-        st += 2 * d
-      elif kind_field != 2:
-        raise ValueError("segment expects an sgd dump, found field %d" % kind_field)
+      field, parts = _DUMP_FIELDS[k]
+      if kind_field != field:
+        raise ValueError("segment expects optimizer dump field %d, found field %d" %
+                         (field, kind_field))
+      r = floats(body, [fno for fno, _ in parts])
+      for fno, slot in parts:
+        if len(r[fno]) != d:
+          raise ValueError("optimizer dump field %d has %d values, expected %d" %
+                           (fno, len(r[fno]), d))
+        row[st + slot * d:st + (slot + 1) * d] = r[fno]
+      st += len(parts) * d
     return rid, row, np.uint32(ts & 0xFFFFFFFF)
 
 

@@ -44,7 +44,14 @@ enum { OPTK_SGD = 0, OPTK_ADAGRAD = 1, OPTK_FTRL = 2, OPTK_MULTI = 3 };
 struct SegDev {
   int dim, opt_kind, w_off, st_off, init_kind;
   float init_acc, wd, l1, l2, beta, init_a, init_b;
+  float momentum, epsilon, rho, conf_lr;
+  int nesterov;
 };
+
+// per-element optimizer state slots of a row: norm | (FTRL) zero; n; accum | accum_update
+__host__ __device__ inline int opt_nstate(int kind) {
+  return kind == MONO_OPT_SGD ? 0 : (kind == MONO_OPT_FTRL || kind == MONO_OPT_ADADELTA) ? 2 : 1;
+}
 
 struct TableDev {  // passed to kernels by value
   int64_t* keys;
@@ -180,8 +187,10 @@ __device__ inline float row_init_value(const TableDev& t, int64_t key, int e) {
   }
   for (int s = 0; s < t.n_seg; ++s) {
     const SegDev& c = t.seg[s];
-    int len = c.opt_kind == MONO_OPT_ADAGRAD ? c.dim : c.opt_kind == MONO_OPT_FTRL ? 2 * c.dim : 0;
-    if (e >= c.st_off && e < c.st_off + len) return (e - c.st_off < c.dim) ? c.init_acc : 0.f;
+    const int len = opt_nstate(c.opt_kind) * c.dim;
+    // Adagrad / FTRL: norm starts at initial_accumulator_value; every other state starts at 0
+    if (e >= c.st_off && e < c.st_off + len)
+      return (e - c.st_off < c.dim && c.opt_kind <= MONO_OPT_FTRL) ? c.init_acc : 0.f;
   }
   return 0.f;
 }
@@ -411,7 +420,7 @@ __device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, fl
     s0 += gg * gg;
     float eff = __fdiv_rn(lr, sqrtf(s0));
     w -= eff * gg;
-  } else {  // ftrl_optimizer.cc:49-72; s0 = norm, s1 = zero
+  } else if (kind == MONO_OPT_FTRL) {  // ftrl_optimizer.cc:49-72; s0 = norm, s1 = zero
     float norm_new = s0 + g * g;
     float sigma = __fdiv_rn(sqrtf(norm_new) - sqrtf(s0), lr);
     s1 += (g - sigma * w);
@@ -420,6 +429,30 @@ __device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, fl
     w = (fabsf(s1) > c.l1)
             ? __fdiv_rn(lr * (sign * c.l1 - s1), (sqrtf(s0) + c.beta + c.l2 * lr))
             : 0.0f;
+  } else if (kind == MONO_OPT_MOMENTUM) {  // momentum_optimizer.cc:49-72; s0 = n
+    const float dx = lr * (g + c.wd * w);
+    const float new_n = c.momentum * s0 - dx;
+    if (c.nesterov) w += -c.momentum * s0 + (1 + c.momentum) * new_n;
+    else w += new_n;
+    s0 = new_n;
+  } else if (kind == MONO_OPT_RMSPROP || kind == MONO_OPT_RMSPROP_V2) {
+    // rmsprop_optimizer.cc:46-63 / :119-137: the update is carried in double; V1 divides the
+    // CONFIG learning rate and weights dx^2 by (1 - momentum), V2 uses the call's rate
+    const double dx = (double)g + (double)c.wd * (double)w;
+    const double mom = (double)c.momentum;
+    const float new_n = kind == MONO_OPT_RMSPROP ? (float)(mom * (double)s0 + (1 - mom) * dx * dx)
+                                                 : (float)(mom * (double)s0 + dx * dx);
+    const double rate = kind == MONO_OPT_RMSPROP ? (double)c.conf_lr : (double)lr;
+    const double eta = rate / (double)(sqrtf(new_n) + 1);
+    w = (float)((double)w - eta * dx);
+    s0 = new_n;
+  } else {  // adadelta_optimizer.cc:50-66; s0 = accum, s1 = accum_update
+    const float cur = g + c.wd * w;
+    const float new_accum = s0 * c.rho + cur * cur * (1 - c.rho);
+    const float update = __fdiv_rn(sqrtf(s1 + c.epsilon), sqrtf(new_accum + c.epsilon)) * cur;
+    w = w - update * lr;
+    s1 = s1 * c.rho + update * update * (1 - c.rho);
+    s0 = new_accum;
   }
 }
 
@@ -579,8 +612,8 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
 #pragma unroll
       for (int q = 0; q < V; ++q) {
         w[q] = row_init_value(t, key, e0 + q);
-        s0[q] = kind[q] != MONO_OPT_SGD ? row_init_value(t, key, st0_off[q]) : 0.f;
-        s1[q] = kind[q] == MONO_OPT_FTRL ? row_init_value(t, key, st1_off[q]) : 0.f;
+        s0[q] = opt_nstate(kind[q]) >= 1 ? row_init_value(t, key, st0_off[q]) : 0.f;
+        s1[q] = opt_nstate(kind[q]) == 2 ? row_init_value(t, key, st1_off[q]) : 0.f;
       }
     } else {
       vload<V>(w, row + e0);
@@ -590,8 +623,8 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
         if (OPTK == OPTK_MULTI) {
 #pragma unroll
           for (int q = 0; q < V; ++q) {
-            s0[q] = kind[q] != MONO_OPT_SGD ? row[st0_off[q]] : 0.f;
-            s1[q] = kind[q] == MONO_OPT_FTRL ? row[st1_off[q]] : 0.f;
+            s0[q] = opt_nstate(kind[q]) >= 1 ? row[st0_off[q]] : 0.f;
+            s1[q] = opt_nstate(kind[q]) == 2 ? row[st1_off[q]] : 0.f;
           }
         }
       }
@@ -645,8 +678,8 @@ __global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
       if (OPTK == OPTK_MULTI) {
 #pragma unroll
         for (int q = 0; q < V; ++q) {
-          if (kind[q] != MONO_OPT_SGD) row[st0_off[q]] = s0[q];
-          if (kind[q] == MONO_OPT_FTRL) row[st1_off[q]] = s1[q];
+          if (opt_nstate(kind[q]) >= 1) row[st0_off[q]] = s0[q];
+          if (opt_nstate(kind[q]) == 2) row[st1_off[q]] = s1[q];
         }
       }
     }
@@ -769,13 +802,13 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
       if (owner && !part) {
         if (ls.fresh) {
           w = row_init_value(t, ls.key, e);
-          s0 = kind != MONO_OPT_SGD ? row_init_value(t, ls.key, st0) : 0.f;
-          s1 = kind == MONO_OPT_FTRL ? row_init_value(t, ls.key, st1) : 0.f;
+          s0 = opt_nstate(kind) >= 1 ? row_init_value(t, ls.key, st0) : 0.f;
+          s1 = opt_nstate(kind) == 2 ? row_init_value(t, ls.key, st1) : 0.f;
         } else {
           w = row[e];
           if (need_state) {
-            s0 = kind != MONO_OPT_SGD ? row[st0] : 0.f;
-            s1 = kind == MONO_OPT_FTRL ? row[st1] : 0.f;
+            s0 = opt_nstate(kind) >= 1 ? row[st0] : 0.f;
+            s1 = opt_nstate(kind) == 2 ? row[st1] : 0.f;
           }
         }
       }
@@ -914,8 +947,8 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         if (MODE == MODE_OPT_DEDUP) opt_step(kind, sg, lr, acc, w, s0, s1);
         row[e] = w;
         if (need_state || ls.fresh) {
-          if (kind != MONO_OPT_SGD) row[st0] = s0;
-          if (kind == MONO_OPT_FTRL) row[st1] = s1;
+          if (opt_nstate(kind) >= 1) row[st0] = s0;
+          if (opt_nstate(kind) == 2) row[st1] = s1;
         }
       }
     }
@@ -945,13 +978,13 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
       float w, s0 = 0.f, s1 = 0.f;
       if (sp.fresh) {
         w = row_init_value(t, sp.key, e);
-        s0 = kind != MONO_OPT_SGD ? row_init_value(t, sp.key, st0) : 0.f;
-        s1 = kind == MONO_OPT_FTRL ? row_init_value(t, sp.key, st1) : 0.f;
+        s0 = opt_nstate(kind) >= 1 ? row_init_value(t, sp.key, st0) : 0.f;
+        s1 = opt_nstate(kind) == 2 ? row_init_value(t, sp.key, st1) : 0.f;
       } else {
         w = row[e];
         if (need_state) {
-          s0 = kind != MONO_OPT_SGD ? row[st0] : 0.f;
-          s1 = kind == MONO_OPT_FTRL ? row[st1] : 0.f;
+          s0 = opt_nstate(kind) >= 1 ? row[st0] : 0.f;
+          s1 = opt_nstate(kind) == 2 ? row[st1] : 0.f;
         }
       }
       const float* pp = a.partials + (uint64_t)sp.pbase * D + e;
@@ -964,8 +997,8 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
       }
       row[e] = w;
       if (need_state || sp.fresh) {
-        if (kind != MONO_OPT_SGD) row[st0] = s0;
-        if (kind == MONO_OPT_FTRL) row[st1] = s1;
+        if (opt_nstate(kind) >= 1) row[st0] = s0;
+        if (opt_nstate(kind) == 2) row[st1] = s1;
       }
     }
     if (threadIdx.x == 0 && t.ts) t.ts[sp.slot] = a.ts;
@@ -1428,7 +1461,7 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
   int w = 0;
   for (int s = 0; s < cfg->n_segments; ++s) {
     const mono_segment_cfg& c = cfg->segments[s];
-    if (c.dim <= 0 || c.opt_kind < 0 || c.opt_kind > MONO_OPT_FTRL || c.init_kind < 0 ||
+    if (c.dim <= 0 || c.opt_kind < 0 || c.opt_kind > MONO_OPT_ADADELTA || c.init_kind < 0 ||
         c.init_kind > MONO_INIT_UNIFORM) {
       delete t;
       return fail("mono_table_create: bad segment %d (dim %d opt %d init %d)", s, c.dim,
@@ -1447,13 +1480,18 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
     sd.dim = c.dim; sd.opt_kind = c.opt_kind; sd.w_off = wo; sd.st_off = st;
     sd.init_kind = c.init_kind; sd.init_acc = c.init_acc; sd.wd = c.weight_decay;
     sd.l1 = c.l1; sd.l2 = c.l2; sd.beta = c.beta; sd.init_a = c.init_a; sd.init_b = c.init_b;
+    sd.momentum = c.momentum; sd.epsilon = c.epsilon; sd.rho = c.averaging_ratio;
+    sd.conf_lr = c.learning_rate; sd.nesterov = c.use_nesterov;
     wo += c.dim;
-    st += c.opt_kind == MONO_OPT_ADAGRAD ? c.dim : c.opt_kind == MONO_OPT_FTRL ? 2 * c.dim : 0;
+    st += opt_nstate(c.opt_kind) * c.dim;
   }
   d.row_floats = st;
   d.seed = cfg->seed;
   d.default_expire_days = cfg->default_expire_days;
-  t->opt_tmpl = cfg->n_segments == 1 ? cfg->segments[0].opt_kind : OPTK_MULTI;
+  // the three reference-config optimizers have specialised kernels; the rest (and mixes) take
+  // the generic per-element path
+  t->opt_tmpl = cfg->n_segments == 1 && cfg->segments[0].opt_kind <= MONO_OPT_FTRL
+                    ? cfg->segments[0].opt_kind : OPTK_MULTI;
   // floats per lane: the widest access that still keeps all 8 lanes of a sub-group busy
   t->vec = 1;
   if (cfg->n_segments == 1) {

@@ -1,5 +1,5 @@
 """Config builders mirroring monolith/native_training/entry.py:54-588 as plain dataclasses
-(no protobuf): optimizers (Sgd / Adagrad / Ftrl), initializers (Zeros / Constants /
+(no protobuf): optimizers (Sgd / Adagrad / Ftrl / Momentum / Rmsprop / RmspropV2 / Adadelta), initializers (Zeros / Constants /
 RandomUniform), CombineAsSegment, CuckooHashTableConfig, HashTableConfigInstance, and the
 table / slot-expire / slot-threshold messages of embedding_hash_table.proto:19-106.
 Defaults are the proto defaults (optimizer.proto:19-72, initializer_config.proto:19-46)."""
@@ -8,6 +8,7 @@ import dataclasses
 from typing import Any, Callable, Dict, List, Optional, Union
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
+OPT_MOMENTUM, OPT_RMSPROP, OPT_RMSPROP_V2, OPT_ADADELTA = 3, 4, 5, 6
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT, INIT_UNIFORM = 0, 1, 2, 3
 
 
@@ -40,6 +41,44 @@ class FtrlOptimizer(Optimizer):  # entry.py:342-369
   l1_regularization: Optional[float] = None
   l2_regularization: Optional[float] = None
   kind = OPT_FTRL
+
+
+@dataclasses.dataclass
+class AdadeltaOptimizer(Optimizer):  # entry.py:112-131, optimizer.proto:90-97
+  learning_rate: Optional[Any] = None
+  weight_decay_factor: float = 0.0
+  averaging_ratio: float = 0.9
+  epsilon: float = 0.01
+  warmup_steps: int = 0
+  kind = OPT_ADADELTA
+
+
+@dataclasses.dataclass
+class MomentumOptimizer(Optimizer):  # entry.py:226-244, optimizer.proto:142-149
+  learning_rate: Optional[Any] = None
+  weight_decay_factor: float = 0.0
+  use_nesterov: bool = False
+  momentum: float = 0.9
+  warmup_steps: int = 0
+  kind = OPT_MOMENTUM
+
+
+@dataclasses.dataclass
+class RmspropOptimizer(Optimizer):  # entry.py:258-269, optimizer.proto:169-174
+  """The kernel divides the CONFIG learning rate (proto default 0.01 when it is not a plain
+  number), not the per-call learning-rate tensor (rmsprop_optimizer.cc:59)."""
+  learning_rate: Optional[Any] = None
+  weight_decay_factor: float = 0.0
+  momentum: float = 0.9
+  kind = OPT_RMSPROP
+
+
+@dataclasses.dataclass
+class RmspropV2Optimizer(Optimizer):  # entry.py:272-283, optimizer.proto:180-185
+  learning_rate: Optional[Any] = None
+  weight_decay_factor: float = 0.0
+  momentum: float = 0.9
+  kind = OPT_RMSPROP_V2
 
 
 class Initializer:

@@ -83,7 +83,9 @@ class _TableResource:
     segs = []
     for s in table_config.segments:
       o, i = s.opt_config, s.init_config
-      if not isinstance(o, (entry.SgdOptimizer, entry.AdagradOptimizer, entry.FtrlOptimizer)):
+      if not isinstance(o, (entry.SgdOptimizer, entry.AdagradOptimizer, entry.FtrlOptimizer,
+                            entry.MomentumOptimizer, entry.RmspropOptimizer,
+                            entry.RmspropV2Optimizer, entry.AdadeltaOptimizer)):
         raise ValueError("optimizer %r is out of scope of the MI355X hot path" % (o,))
       init_acc = getattr(o, "initial_accumulator_value", None)
       seg = _lib.SegCfg(
@@ -92,6 +94,12 @@ class _TableResource:
           getattr(o, "l1_regularization", None) or 0.0,
           getattr(o, "l2_regularization", None) or 0.0,
           getattr(o, "beta", None) or 0.0, i.kind, 0.0, 0.0)
+      seg.momentum = getattr(o, "momentum", 0.9)
+      seg.epsilon = getattr(o, "epsilon", 0.01)
+      seg.averaging_ratio = getattr(o, "averaging_ratio", 0.9)
+      conf_lr = getattr(o, "learning_rate", None)  # _convert_to_proto keeps plain numbers only
+      seg.learning_rate = float(conf_lr) if isinstance(conf_lr, (int, float)) else 0.01
+      seg.use_nesterov = int(bool(getattr(o, "use_nesterov", False)))
       if isinstance(i, entry.ConstantsInitializer):
         seg.init_a = i.constant
       elif isinstance(i, entry.RandomUniformInitializer):

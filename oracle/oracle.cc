@@ -29,7 +29,8 @@
 
 namespace {
 
-enum { OPT_SGD = 0, OPT_ADAGRAD = 1, OPT_FTRL = 2 };
+enum { OPT_SGD = 0, OPT_ADAGRAD = 1, OPT_FTRL = 2, OPT_MOMENTUM = 3, OPT_RMSPROP = 4,
+       OPT_RMSPROP_V2 = 5, OPT_ADADELTA = 6 };
 enum { INIT_ZEROS = 0, INIT_ONES = 1, INIT_CONSTANT = 2, INIT_UNIFORM = 3 };
 
 struct SegCfg {  // == mono_segment_cfg
@@ -40,7 +41,18 @@ struct SegCfg {  // == mono_segment_cfg
   float l1, l2, beta;
   int32_t init_kind;
   float init_a, init_b;
+  float momentum, epsilon, averaging_ratio, learning_rate;
+  int32_t use_nesterov;
 };
+
+// floats of optimizer context per weight: SizeBytes() of the reference optimizers
+inline int state_slots(int kind) {
+  switch (kind) {
+    case OPT_SGD: return 0;
+    case OPT_FTRL: case OPT_ADADELTA: return 2;
+    default: return 1;
+  }
+}
 
 struct TableCfg {  // == mono_table_cfg
   int32_t n_segments;
@@ -257,6 +269,8 @@ struct Table {
           st[i] = c.init_acc;
           st[c.dim + i] = 0.f;
         }
+      } else {  // momentum / rmsprop / adadelta Init: every context float = 0
+        for (int i = 0; i < state_slots(c.opt_kind) * c.dim; ++i) st[i] = 0.f;
       }
     }
   }
@@ -287,6 +301,59 @@ struct Table {
           norm[i] += gg * gg;
           float effective_lr = lr / std::sqrt(norm[i]);
           num[i] -= effective_lr * gg;
+        }
+      } else if (c.opt_kind == OPT_MOMENTUM) {  // momentum_optimizer.cc:49-72
+        float* n = st;
+        for (int i = 0; i < c.dim; ++i) {
+          float dx = lr * (g[i] + c.weight_decay * num[i]);
+          float new_n = n[i];
+          float new_w = num[i];
+          if (c.use_nesterov) {
+            float prev_n = new_n;
+            new_n = c.momentum * new_n - dx;
+            new_w += -c.momentum * prev_n + (1 + c.momentum) * new_n;
+          } else {
+            new_n = c.momentum * new_n - dx;
+            new_w += new_n;
+          }
+          n[i] = new_n;
+          num[i] = new_w;
+        }
+      } else if (c.opt_kind == OPT_RMSPROP || c.opt_kind == OPT_RMSPROP_V2) {
+        // rmsprop_optimizer.cc:46-63 (V1: config learning rate, (1 - momentum) dx^2) and
+        // :119-137 (V2: the call's learning rate, plain dx^2); mixed float / double as written
+        float* n = st;
+        for (int i = 0; i < c.dim; ++i) {
+          const float& cur_grad = g[i];
+          float new_n = n[i];
+          float new_w = num[i];
+          double dx = cur_grad + static_cast<double>(c.weight_decay) * new_w;
+          double eta;
+          if (c.opt_kind == OPT_RMSPROP) {
+            new_n = static_cast<double>(c.momentum) * new_n +
+                    (1 - static_cast<double>(c.momentum)) * dx * dx;
+            eta = static_cast<double>(c.learning_rate) / (std::sqrt(new_n) + 1);
+          } else {
+            new_n = static_cast<double>(c.momentum) * new_n + dx * dx;
+            eta = static_cast<double>(lr) / (std::sqrt(new_n) + 1);
+          }
+          new_w -= eta * dx;
+          n[i] = new_n;
+          num[i] = new_w;
+        }
+      } else if (c.opt_kind == OPT_ADADELTA) {  // adadelta_optimizer.cc:50-66
+        float* accum = st;
+        float* accum_update = st + c.dim;
+        for (int i = 0; i < c.dim; ++i) {
+          float cur_grad = g[i] + c.weight_decay * num[i];
+          float new_accum = accum[i] * c.averaging_ratio + cur_grad * cur_grad * (1 - c.averaging_ratio);
+          float update = std::sqrt(accum_update[i] + c.epsilon) / std::sqrt(new_accum + c.epsilon) * cur_grad;
+          float new_w = num[i] - update * lr;
+          float new_accum_update =
+              accum_update[i] * c.averaging_ratio + update * update * (1 - c.averaging_ratio);
+          num[i] = new_w;
+          accum[i] = new_accum;
+          accum_update[i] = new_accum_update;
         }
       } else {  // ftrl_optimizer.cc:49-72
         float* norm = st;
@@ -384,7 +451,7 @@ void* orc_table_create(const TableCfg* cfg) {
   for (int s = 0; s < cfg->n_segments; ++s) {
     t->seg_st_off.push_back(st);
     const SegCfg& c = cfg->segments[s];
-    st += c.opt_kind == OPT_ADAGRAD ? c.dim : c.opt_kind == OPT_FTRL ? 2 * c.dim : 0;
+    st += state_slots(c.opt_kind) * c.dim;
   }
   t->row_floats = st;
   t->default_expire_days = cfg->default_expire_days;

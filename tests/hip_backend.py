@@ -16,6 +16,18 @@ def _opt(d):
   if k == "adagrad":
     return entry.AdagradOptimizer(initial_accumulator_value=d.get("init_acc", 0.1),
                                   weight_decay_factor=d.get("weight_decay", 0.0))
+  if k == "momentum":
+    return entry.MomentumOptimizer(weight_decay_factor=d.get("weight_decay", 0.0),
+                                   use_nesterov=d.get("use_nesterov", False),
+                                   momentum=d.get("momentum", 0.9))
+  if k in ("rmsprop", "rmspropv2"):
+    cls = entry.RmspropOptimizer if k == "rmsprop" else entry.RmspropV2Optimizer
+    return cls(learning_rate=d.get("learning_rate", 0.01),
+               weight_decay_factor=d.get("weight_decay", 0.0), momentum=d.get("momentum", 0.9))
+  if k == "adadelta":
+    return entry.AdadeltaOptimizer(weight_decay_factor=d.get("weight_decay", 0.0),
+                                   averaging_ratio=d.get("averaging_ratio", 0.9),
+                                   epsilon=d.get("epsilon", 0.01))
   return entry.FtrlOptimizer(initial_accumulator_value=d.get("init_acc", 0.1),
                              beta=d.get("beta", 0.0), l1_regularization=d.get("l1", 0.0),
                              l2_regularization=d.get("l2", 0.0))

@@ -6,7 +6,11 @@ def seg_from_dict(d):
   return cpu.seg(d["dim"], d.get("opt", "sgd"), d.get("init", "zeros"),
                  init_acc=d.get("init_acc", 0.1), weight_decay=d.get("weight_decay", 0.0),
                  l1=d.get("l1", 0.0), l2=d.get("l2", 0.0), beta=d.get("beta", 0.0),
-                 init_a=d.get("init_a", 0.0), init_b=d.get("init_b", 0.0))
+                 init_a=d.get("init_a", 0.0), init_b=d.get("init_b", 0.0),
+                 momentum=d.get("momentum", 0.9), epsilon=d.get("epsilon", 0.01),
+                 averaging_ratio=d.get("averaging_ratio", 0.9),
+                 learning_rate=d.get("learning_rate", 0.01),
+                 use_nesterov=d.get("use_nesterov", False))
 
 
 def make_table(cfg):

@@ -37,9 +37,17 @@ def classes():
   _msg(fd, "SgdOptimizerDump", [])
   _msg(fd, "FtrlOptimizerDump", [("zero", 1, F.TYPE_FLOAT, R, None),
                                  ("norm", 2, F.TYPE_FLOAT, R, None)])
+  _msg(fd, "AdadeltaOptimizerDump", [("accum", 1, F.TYPE_FLOAT, R, None),
+                                     ("accum_update", 2, F.TYPE_FLOAT, R, None)])
+  for n in ("MomentumOptimizerDump", "RmspropOptimizerDump", "RmspropV2OptimizerDump"):
+    _msg(fd, n, [("n", 1, F.TYPE_FLOAT, R, None)])
   _msg(fd, "SingleOptimizerDump", [("adagrad", 1, F.TYPE_MESSAGE, O, "AdagradOptimizerDump"),
                                    ("sgd", 2, F.TYPE_MESSAGE, O, "SgdOptimizerDump"),
-                                   ("ftrl", 3, F.TYPE_MESSAGE, O, "FtrlOptimizerDump")])
+                                   ("ftrl", 3, F.TYPE_MESSAGE, O, "FtrlOptimizerDump"),
+                                   ("adadelta", 6, F.TYPE_MESSAGE, O, "AdadeltaOptimizerDump"),
+                                   ("momentum", 9, F.TYPE_MESSAGE, O, "MomentumOptimizerDump"),
+                                   ("rmsprop", 11, F.TYPE_MESSAGE, O, "RmspropOptimizerDump"),
+                                   ("rmspropv2", 12, F.TYPE_MESSAGE, O, "RmspropV2OptimizerDump")])
   _msg(fd, "OptimizerDump", [("dump", 1, F.TYPE_MESSAGE, R, "SingleOptimizerDump")])
   _msg(fd, "EntryDump", [("id", 1, F.TYPE_SFIXED64, O, None), ("num", 2, F.TYPE_FLOAT, R, None),
                          ("opt", 3, F.TYPE_MESSAGE, O, "OptimizerDump"),
@@ -75,6 +83,14 @@ def _entry_msg(cls, layout, rid, row, ts):
       s.ftrl.zero.extend(float(x) for x in row[cur + d:cur + 2 * d])
       s.ftrl.norm.extend(float(x) for x in row[cur:cur + d])
       cur += 2 * d
+    elif kind == ck.ADADELTA:
+      s.adadelta.accum.extend(float(x) for x in row[cur:cur + d])
+      s.adadelta.accum_update.extend(float(x) for x in row[cur + d:cur + 2 * d])
+      cur += 2 * d
+    elif kind in (ck.MOMENTUM, ck.RMSPROP, ck.RMSPROP_V2):
+      sub = {ck.MOMENTUM: s.momentum, ck.RMSPROP: s.rmsprop, ck.RMSPROP_V2: s.rmspropv2}[kind]
+      sub.n.extend(float(x) for x in row[cur:cur + d])
+      cur += d
     else:
       s.sgd.SetInParent()
   m.last_update_ts_sec = int(ts)
@@ -82,7 +98,8 @@ def _entry_msg(cls, layout, rid, row, ts):
 
 
 def test_entry_dump_encoder_equals_protobuf(classes):
-  layout = ck.DumpLayout([(3, ck.ADAGRAD), (2, ck.FTRL), (4, ck.SGD), (1, ck.ADAGRAD)])
+  layout = ck.DumpLayout([(3, ck.ADAGRAD), (2, ck.FTRL), (4, ck.SGD), (1, ck.ADAGRAD),
+                          (2, ck.ADADELTA), (3, ck.MOMENTUM), (1, ck.RMSPROP), (2, ck.RMSPROP_V2)])
   rng = np.random.Generator(np.random.PCG64(11))
   n = 64
   ids = rng.integers(-2**62, 2**62, n)

@@ -1,0 +1,145 @@
+"""Momentum, RMSProp, RMSPropV2, Adadelta.
+
+CPU: the oracle against the reference's unit-test vectors (momentum_optimizer_test.cc:32-70,
+rmsprop_optimizer_test.cc:32-70, adadelta_optimizer_test.cc:32-70; FloatNear 1e-6 there too).
+GPU: the HIP table against the oracle, bit for bit, on random streams (single-optimizer tables,
+mixed multi-segment entries, dedup / no dedup, hot keys), and the dump format round trip."""
+import numpy as np
+import pytest
+
+from oracle import cpu
+from tests import oracle_backend
+
+
+def _steps(opt, dim, grads, lr=0.01, **kw):
+  t = cpu.OracleTable([cpu.seg(dim, opt, **kw)])
+  out = []
+  for g in grads:
+    t.apply_gradients(np.array([7], np.int64), np.array([g], np.float32), [lr])
+    ids, rows, _ = t.export()
+    out.append(rows[0].copy())
+  return out
+
+
+def test_momentum_reference_vectors():
+  r = _steps("momentum", 1, [[10.0], [10.0]])
+  assert abs(r[0][0] - -0.1) < 1e-6 and abs(r[0][1] - -0.1) < 1e-4   # w, n
+  assert abs(r[1][0] - -0.29) < 1e-6
+  r = _steps("momentum", 2, [[10.0, 1.0], [10.0, 1.0]])
+  assert np.allclose(r[0][:2], [-0.1, -0.01], atol=1e-6) and np.allclose(r[0][2:], [-0.1, -0.01], atol=1e-4)
+  assert np.allclose(r[1][:2], [-0.29, -0.029], atol=1e-6)
+
+
+def test_rmsprop_reference_vectors():
+  r = _steps("rmsprop", 1, [[10.0], [10.0]])
+  assert abs(r[0][0] - -0.024025) < 1e-6 and abs(r[0][1] - 10) < 1e-4
+  assert abs(r[1][0] - -0.042686) < 1e-6
+  # V1 ignores the per-call learning rate (rmsprop_optimizer.cc:59 reads the config value)
+  r2 = _steps("rmsprop", 1, [[10.0], [10.0]], lr=123.0)
+  assert r2[1][0] == r[1][0]
+  r = _steps("rmspropv2", 2, [[10.0, 1.0], [10.0, 1.0]])
+  assert np.allclose(r[0][:2], [-0.0090909, -0.005], atol=1e-6) and np.allclose(r[0][2:], [100, 1], atol=1e-4)
+  assert np.allclose(r[1][:2], [-0.0158549, -0.0092045], atol=1e-6)
+
+
+def test_adadelta_reference_vectors():
+  r = _steps("adadelta", 1, [[10.0], [10.0]])
+  assert abs(r[0][0] - -0.0031607) < 1e-6 and abs(r[0][1] - 10) < 1e-4
+  assert abs(r[1][0] - -0.0064035) < 1e-6
+  r = _steps("adadelta", 2, [[10.0, 1.0], [10.0, 1.0]])
+  assert np.allclose(r[0][:2], [-0.0031607, -0.0030151], atol=1e-6)
+  assert np.allclose(r[0][2:4], [10, 0.1], atol=1e-4)
+  assert np.allclose(r[1][:2], [-0.0064035, -0.0061047], atol=1e-6)
+
+
+def test_dump_layout_of_new_optimizers_matches_protobuf_field_numbers():
+  """optimizer.proto:216-231: adadelta = 6 {accum 1, accum_update 2}, momentum = 9 {n 1},
+  rmsprop = 11 {n 1}, rmspropv2 = 12 {n 1}."""
+  from monolith_amd import checkpoint as ck
+  layout = ck.DumpLayout([(2, ck.MOMENTUM), (1, ck.ADADELTA), (1, ck.RMSPROP), (1, ck.RMSPROP_V2)])
+  assert layout.row_floats == 5 + 2 + 2 + 1 + 1
+  rows = np.arange(11, dtype=np.float32).reshape(1, 11) + 0.5
+  (rec,) = layout.encode(np.array([3], np.int64), rows, np.array([9], np.uint32))
+  b = rec[0].tobytes()
+  import struct
+  f = lambda *xs: b"".join(bytes([t]) + struct.pack("<f", v) for t, v in xs)
+  mom = f((0x0d, 5.5), (0x0d, 6.5))
+  ada = f((0x0d, 7.5), (0x15, 8.5))
+  rms, rms2 = f((0x0d, 9.5)), f((0x0d, 10.5))
+  single = lambda field, body: bytes([(field << 3) | 2, len(body)]) + body
+  opt = b"".join(bytes([0x0a, len(s)]) + s for s in
+                 (single(9, mom), single(6, ada), single(11, rms), single(12, rms2)))
+  exp = b"\x09" + struct.pack("<q", 3) + f(*[(0x15, v + 0.5) for v in range(5)]) + \
+      bytes([0x1a, len(opt)]) + opt + b"\x20\x09"
+  assert b == exp
+  rid, row, ts = layout._decode_one(b)
+  assert rid == 3 and ts == 9 and np.array_equal(row, rows[0])
+
+
+# ------------------------------------------------------------------------------------------ GPU
+CASES = {
+    "momentum": {"segments": [{"dim": 16, "opt": "momentum", "weight_decay": 0.01, "init": "uniform",
+                               "init_a": -0.1, "init_b": 0.1}], "seed": 3},
+    "nesterov": {"segments": [{"dim": 8, "opt": "momentum", "use_nesterov": True, "momentum": 0.8,
+                               "init": "ones"}]},
+    "rmsprop": {"segments": [{"dim": 32, "opt": "rmsprop", "learning_rate": 0.05,
+                              "weight_decay": 0.001, "init": "uniform", "init_a": -0.1, "init_b": 0.1}]},
+    "rmspropv2": {"segments": [{"dim": 5, "opt": "rmspropv2", "momentum": 0.5, "init": "constant",
+                                "init_a": 0.25}]},
+    "adadelta": {"segments": [{"dim": 16, "opt": "adadelta", "epsilon": 1e-3,
+                               "averaging_ratio": 0.95, "weight_decay": 0.01, "init": "uniform",
+                               "init_a": -0.1, "init_b": 0.1}]},
+    "mixed": {"segments": [{"dim": 1, "opt": "ftrl", "init_acc": 0.1, "beta": 1.0},
+                           {"dim": 3, "opt": "adadelta"}, {"dim": 4, "opt": "momentum"},
+                           {"dim": 2, "opt": "rmsprop"}, {"dim": 6, "opt": "adagrad"},
+                           {"dim": 2, "opt": "rmspropv2"}, {"dim": 2, "opt": "sgd"}]},
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("dedup", [False, True])
+def test_hip_matches_oracle(name, dedup):
+  from tests import hip_backend
+  cfg = CASES[name]
+  o, h = oracle_backend.make_table(cfg), hip_backend.make_table(cfg)
+  n_seg = len(cfg["segments"])
+  dim = sum(s["dim"] for s in cfg["segments"])
+  rng = np.random.Generator(np.random.PCG64(hash(name) % 1000 + int(dedup)))
+  for step in range(6):
+    n = 3000
+    ids = rng.zipf(1.3, n).astype(np.int64) % 700 - 50
+    if step == 3:
+      ids[::3] = 5  # a hot key: 1000 occurrences, walks the long-segment kernel
+    g = rng.normal(0, 0.3, (n, dim)).astype(np.float32)
+    lrs = [0.01 * (s + 1) for s in range(n_seg)]
+    for t in (o, h):
+      t.apply_gradients(ids, g, lrs, req_time=100 + step, global_step=step, enable_dedup=dedup)
+    probe = np.arange(-60, 720, dtype=np.int64)
+    assert np.array_equal(o.lookup(probe).view(np.uint32), h.lookup(probe).view(np.uint32)), step
+  oi, orows, ots = o.export()
+  hi, hrows, hts = h.export()
+  assert np.array_equal(oi, hi) and np.array_equal(ots, hts)
+  assert np.array_equal(orows.view(np.uint32), hrows.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_new_optimizer_tables_save_and_restore(tmp_path):
+  import torch
+  from monolith_amd import checkpoint as ck
+  from tests import hip_backend
+  cfg = CASES["mixed"]
+  h = hip_backend.make_table(cfg)
+  rng = np.random.Generator(np.random.PCG64(2))
+  ids = rng.integers(-100, 100, 500).astype(np.int64)
+  h.apply_gradients(ids, rng.normal(0, 1, (500, 20)).astype(np.float32), [0.01] * 7, req_time=77)
+  base = str(tmp_path / "t")
+  h.t.save(base)
+  h2 = hip_backend.make_table(cfg)
+  h2.t = h2.t.restore(base)
+  a, b = h.export(), h2.export()
+  for x, y in zip(a, b):
+    assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                          y.view(np.uint32) if y.dtype == np.float32 else y)
+  layout = ck.DumpLayout.from_table_config(hip_backend.table_config(cfg))
+  assert layout.row_floats == h.row_floats == 20 + 2 + 6 + 4 + 2 + 6 + 2
