@@ -101,6 +101,19 @@ int mono_filter_import_split(void* filter, int split, const uint16_t* h_cells, i
 int mono_filter_set_state(void* filter, int64_t head, int64_t head_increment, int64_t failure_count,
                           void* stream);
 
+/* ---- touched-key set: runtime/hopscotch/hopscotch_hash_set.{h,cc},
+ *      ops/touched_key_set_{op,insert_op,steal_op}.cc, touched_key_set_ops.py ----
+ * insert: the keys go in one by one, in input order; whenever an insert finds MORE than
+ * `capacity` keys in the set, the whole set is dropped first (hopscotch_hash_set.cc:113-122);
+ * *h_dropped = keys dropped during the call (MonolithTouchedKeySetInsert's total_dropped_num).
+ * steal: GetAndClear (:168-193): *h_count keys into out_ids (device, room for out_cap), order
+ * unspecified. Both synchronise the stream. */
+int mono_keyset_create(int64_t capacity, void** out_set);
+int mono_keyset_destroy(void* set);
+int mono_keyset_size(void* set, int64_t* out_size);
+int mono_keyset_insert(void* set, const int64_t* ids, int64_t n, int64_t* h_dropped, void* stream);
+int mono_keyset_steal(void* set, int64_t* out_ids, int64_t out_cap, int64_t* h_count, void* stream);
+
 /* ---- table lifetime: ops/hash_table_op.cc:38-131, ops/embedding_hash_table_tf_bridge.cc:48-104 ---- */
 int mono_table_create(const mono_table_cfg* cfg, void** out_table);
 int mono_table_destroy(void* table);

@@ -116,6 +116,7 @@ class _TableResource:
     self.h = C.c_void_p()
     self.filter = hash_filter
     self.config = table_config
+    self.touched_key_set = None  # SetHopscotchHashSet (hash_table_op.cc:90-95)
     _lib.check(_lib.lib.mono_table_create(C.byref(cfg), C.byref(self.h)))
     self.dim = _lib.lib.mono_table_dim(self.h)
     self.row_floats = _lib.lib.mono_table_row_floats(self.h)
@@ -221,7 +222,27 @@ class HashTable(BaseHashTable):
         self._h(), self._filter_h(), _lib.vp(ids), _lib.vp(grads), C.c_int64(ids.numel()), arr,
         C.c_int(len(lrs)), C.c_int64(_scalar(req_time)), C.c_int64(_scalar(global_step)),
         C.c_int(int(bool(enable_dedup))), _lib.stream_ptr()))
+    self._record_touched(ids)
     return self._copy_with_new_table(self._table)
+
+  def set_touched_key_set(self, key_set) -> "HashTable":
+    """EmbeddingHashTableTfBridge::SetHopscotchHashSet (embedding_hash_table_tf_bridge.cc:
+    398-402): from now on every id an optimizer step is applied to is inserted into `key_set`
+    (a touched_key_set_ops.TouchedKeySet); None detaches it."""
+    self._table.touched_key_set = key_set
+    return self
+
+  def _record_touched(self, ids):
+    """embedding_hash_table_tf_bridge.cc:303-307: ids_after_filter go into the touched set. An id
+    the occurrence filter rejected is not in the table afterwards (the gate only applies to
+    unknown ids, :274-275), so "applied" == "contained after the step"."""
+    ks = self._table.touched_key_set
+    if ks is None or ids.numel() == 0:
+      return
+    f = self._table.filter
+    if f is not None and f.kind == "sliding":
+      ids = ids[self.contains(ids)]
+    ks.insert(ids)
 
   def as_op(self):
     return self._table
@@ -412,6 +433,12 @@ def fused_apply_gradient(tables: List, ids, fused_slot_size, id_grads, id_offset
       C.c_void_p(io.data_ptr()), C.c_void_p(go.data_ptr()), C.c_void_p(lrs.data_ptr()),
       C.c_void_p(lrl.data_ptr()), C.c_int64(_scalar(req_time)), C.c_int64(_scalar(global_step)),
       C.c_int(N), C.c_int(int(bool(enable_grad_accumulation))), _lib.stream_ptr()))
+  for k, t in enumerate(tables):
+    if isinstance(t, HashTable) and t.table.touched_key_set is not None:
+      for n in range(N):
+        lo, cnt = int(io[n * K + k]), int(fss[n * K + k])
+        if cnt:
+          t._record_touched(ids[lo:lo + cnt])
   return tables
 
 
@@ -426,11 +453,17 @@ def hash_table_from_config(config: entry.HashTableConfigInstance,
     hash_filter = hash_filter_ops.create_dummy_hash_filter(name_suffix=name_suffix)
   if len(config.learning_rate_fns) != len(table_config.segments):
     raise ValueError("Size of learning_rate_fns and size of segments must be equal.")
-  return HashTable(_TableResource(table_config, hash_filter), shared_name=hash_table_name,
-                   dim_size=dim_size,
-                   slot_expire_time_config=table_config.slot_expire_time_config,
-                   learning_rate_tensor=list(config.learning_rate_fns),
-                   saver_parallel=saver_parallel, extra_restore_names=config.extra_restore_names)
+  table = HashTable(_TableResource(table_config, hash_filter), shared_name=hash_table_name,
+                    dim_size=dim_size,
+                    slot_expire_time_config=table_config.slot_expire_time_config,
+                    learning_rate_tensor=list(config.learning_rate_fns),
+                    saver_parallel=saver_parallel, extra_restore_names=config.extra_restore_names)
+  # ops/hash_table_op.cc:88-95: a table created with a sync client reports its updated ids to the
+  # client's touched-key set. The client itself (gRPC push to serving) is out of scope; any object
+  # with a `touched_key_set` attribute, or a TouchedKeySet, is accepted here.
+  if sync_client is not None:
+    table.set_touched_key_set(getattr(sync_client, "touched_key_set", sync_client))
+  return table
 
 
 _TEST_COUNTER = [0]

@@ -509,3 +509,28 @@ def sharding_sparse_fids(feature_tables, features, ps_num, unique):
       row_splits.append(np.cumsum([0] + [len(part) for part in parts]).astype(np.int64))
   return (fid_list, row_splits, np.array(fid_offset, np.uint64),
           np.array(feature_offset, np.int32), np.array(nfl_offset, np.uint32))
+
+
+# ------------------------------------------------------------------ touched-key set (8f-4)
+class OracleKeySet:
+  """HopscotchHashSet<FID>, sequential (runtime/hopscotch/hopscotch_hash_set.cc:104-193): an
+  insert that finds MORE than `capacity` keys drops the whole set first and reports how many;
+  GetAndClear returns everything. Test infrastructure."""
+
+  def __init__(self, capacity):
+    self.capacity = int(capacity)
+    self.keys = set()
+
+  def insert(self, ids):
+    dropped = 0
+    for k in ids:
+      if len(self.keys) > self.capacity:
+        dropped += len(self.keys)
+        self.keys.clear()
+      self.keys.add(int(k))
+    return dropped
+
+  def steal(self):
+    out = sorted(self.keys)
+    self.keys.clear()
+    return out
