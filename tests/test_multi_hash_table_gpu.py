@@ -1,0 +1,80 @@
+"""MultiHashTable (multi_hash_table_ops.py) on the HIP tables: the reference's test vectors
+(multi_hash_table_ops_test.py:52-113) and the raw ragged API against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from monolith_amd import entry, multi_hash_table_ops as mht
+from oracle import cpu
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg(dim, lr=1.0, opt=None):
+  tc = entry.EmbeddingHashTableConfig(segments=[entry.CombineAsSegment(
+      dim, entry.ZerosInitializer(), opt or entry.SgdOptimizer())])
+  return entry.HashTableConfigInstance(tc, [lr])
+
+
+def _id(x):
+  return torch.tensor(x, dtype=torch.int64, device=DEV)
+
+
+def _value(x):
+  return torch.tensor(x, dtype=torch.float32, device=DEV)
+
+
+def test_lookup_assign_add():
+  t = mht.MultiHashTable.from_configs({"slot0": _cfg(1), "not_used": _cfg(2), "slot1": _cfg(2),
+                                       "slot2": _cfg(2)}, name_suffix="a")
+  assert t.table_names == ("not_used", "slot0", "slot1", "slot2")
+  t = t.assign_add({"slot0": (_id([0]), _value([[1]])), "slot1": (_id([1]), _value([[2, 2]])),
+                    "slot2": (_id([2, 3]), _value([[4, 4], [8, 8]]))})
+  out = t.lookup({"slot0": _id([0]), "slot1": _id([1]), "slot2": _id([2, 3])})
+  assert sorted(out) == ["slot0", "slot1", "slot2"]
+  assert out["slot0"].cpu().tolist() == [[1]]
+  assert out["slot1"].cpu().tolist() == [[2, 2]]
+  assert out["slot2"].cpu().tolist() == [[4, 4], [8, 8]]
+
+
+def test_apply_gradients():
+  t = mht.MultiHashTable.from_configs({"slot0": _cfg(1), "slot1": _cfg(2)}, name_suffix="b")
+  t = t.apply_gradients({"slot0": (_id([0]), _value(2.0)),
+                         "slot1": (_id([1, 2]), _value([[1.0, 3.0], [2.0, 4.0]]))}, global_step=0)
+  out = t.lookup({"slot0": _id([0]), "slot1": _id([1, 2])})
+  assert out["slot0"].cpu().tolist() == [[-2]]
+  assert out["slot1"].cpu().tolist() == [[-1, -3], [-2, -4]]
+
+
+def test_raw_api_matches_oracle():
+  opts = {"a": (4, entry.AdagradOptimizer(initial_accumulator_value=0.1), "adagrad", 0.1),
+          "b": (2, entry.SgdOptimizer(), "sgd", 0.5),
+          "c": (3, entry.FtrlOptimizer(initial_accumulator_value=0.1, beta=1.0), "ftrl", 0.02)}
+  t = mht.MultiHashTable.from_configs({k: _cfg(d, lr, o) for k, (d, o, _, lr) in opts.items()},
+                                      name_suffix="c")
+  model = {k: cpu.OracleTable([cpu.seg(d, name, beta=1.0 if name == "ftrl" else 0.0)])
+           for k, (d, _, name, _) in opts.items()}
+  rng = np.random.Generator(np.random.PCG64(6))
+  for step in range(4):
+    ids = {k: rng.integers(-30, 30, int(rng.integers(0, 200))).astype(np.int64) for k in opts}
+    if step == 2:
+      ids["b"] = np.zeros(0, np.int64)
+    grads = {k: rng.normal(0, 1, (len(ids[k]), opts[k][0])).astype(np.float32) for k in opts}
+    ragged = t.get_ragged_id({k: _id(v) for k, v in ids.items()})
+    assert ragged.row_splits.cpu().tolist() == np.cumsum([0] + [len(ids[k]) for k in "abc"]).tolist()
+    flat = t.raw_lookup(ragged)
+    exp = np.concatenate([model[k].lookup(ids[k]).reshape(-1) for k in "abc"])
+    assert np.array_equal(flat.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    t = t.raw_apply_gradients(ragged, t.get_flat_value({k: _value(v) for k, v in grads.items()}),
+                              global_step=step, req_time=50 + step)
+    for k in "abc":
+      model[k].apply_gradients(ids[k], grads[k], [opts[k][3]], req_time=50 + step, global_step=step)
+  probe = np.arange(-30, 30, dtype=np.int64)
+  out = t.lookup({k: _id(probe) for k in "abc"})
+  for k in "abc":
+    assert np.array_equal(out[k].cpu().numpy().view(np.uint32), model[k].lookup(probe).view(np.uint32))
+  t2 = t.raw_assign(t.get_ragged_id({"b": _id([7, 8])}), _value([1, 2, 3, 4]))
+  assert t2.lookup({"b": _id([8, 7])})["b"].cpu().tolist() == [[3, 4], [1, 2]]
+  with pytest.raises(NotImplementedError):
+    t.save("x")
