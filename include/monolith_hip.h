@@ -101,6 +101,11 @@ int mono_filter_import_split(void* filter, int split, const uint16_t* h_cells, i
 int mono_filter_set_state(void* filter, int64_t head, int64_t head_increment, int64_t failure_count,
                           void* stream);
 
+/* Debug aid without a counterpart in the reference: 1 if a workgroup of the most recent fused
+ * radix-sort pass (csrc/sort.hip) gave up waiting for its predecessors, 0 otherwise, -1 on a HIP
+ * error. Synchronises the device. */
+int mono_debug_sort_error(void);
+
 /* ---- touched-key set: runtime/hopscotch/hopscotch_hash_set.{h,cc},
  *      ops/touched_key_set_{op,insert_op,steal_op}.cc, touched_key_set_ops.py ----
  * insert: the keys go in one by one, in input order; whenever an insert finds MORE than

@@ -3,8 +3,16 @@
 // Every grouping step of the hot path (occurrences by table slot, by fused-embedding offset, by
 // shard * M + slot, by pooling row) is a stable sort of at most a few million 8-byte pairs on
 // 1..29 key bits. At that size a general-purpose library sort is launch-bound (buffer fills and
-// look-back state between passes); this one is three small kernels per 8-bit pass, no spinning:
+// look-back state between passes). Two paths, both 8-bit digits over 8192-element tiles:
 //
+// up to 512 tiles (4.19 M pairs: every sort of the headline workload) — ONE kernel per pass:
+//   k_sort_ghist    digit totals of the first pass
+//   k_sort_fused    ranks its tile, publishes the tile's digit counts as self-validating words
+//                   (count | ready bit: no fence, an agent-scope fence here writes back a whole
+//                   XCD L2), sums the counts of the tiles before it (tile numbers come from an
+//                   atomic ticket, so those tiles are already running and never wait before they
+//                   publish), accumulates the NEXT pass's digit totals, scatters
+// beyond that — three small kernels per pass, no spinning:
 //   k_sort_hist     per-tile digit histogram (LDS)
 //   k_sort_scan     per digit: running count over the preceding tiles, and the digit total
 //   k_sort_scatter  stable in-tile ranking with wave ballots, tile staged in digit order in LDS,
@@ -17,6 +25,7 @@
 // digits keep the runs a tile contributes to one digit at ~32 elements (128 B): with 10-bit
 // digits the scatter degenerates into 16-byte partial-line writes and runs 2x slower.
 #include <algorithm>
+#include <cstdlib>
 
 #include "mono_common.h"
 
@@ -181,6 +190,197 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
   }
 }
 
+
+// ------------------------------------------------------------------------------ fused passes
+// For up to kFusedMaxTiles tiles one kernel per pass replaces hist + scan + scatter ("onesweep"
+// without the chained scan): the digit totals of ALL passes come from one upfront histogram of
+// the input keys; inside a pass every workgroup ranks its tile, publishes the tile's digit counts
+// and a ready flag, waits for the flags of the tiles before it, and sums their counts itself.
+// Tile numbers are handed out by an atomic ticket, so every tile a workgroup waits for has
+// already started and publishes before it waits on anything: the wait always ends. The spin is
+// bounded all the same; a time-out raises err[0] (mono_sort_error) instead of hanging the GPU.
+constexpr int kFusedMaxTiles = 512;
+constexpr int kFusedMaxPasses = 4;
+constexpr uint32_t kSpinLimit = 1u << 22;
+constexpr uint32_t kRowReady = 0x80000000u;  // a tile holds at most 8192 elements
+
+struct FusedPass {
+  int shift[kFusedMaxPasses];
+  int bits[kFusedMaxPasses];
+  int passes;
+};
+
+__global__ void __launch_bounds__(kSortThreads) k_sort_ghist(const uint32_t* __restrict__ keys,
+                                                             int64_t n, int shift, int bits,
+                                                             uint32_t* __restrict__ dhist) {
+  __shared__ uint32_t h[kSortMaxDigits];
+  for (int i = threadIdx.x; i < kSortMaxDigits; i += kSortThreads) h[i] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kSortTile;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t i = base + r * kSortThreads + threadIdx.x;
+    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (uint32_t)((1 << bits) - 1)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSortMaxDigits; i += kSortThreads)
+    if (h[i]) atomicAdd(&dhist[i], h[i]);
+}
+
+__global__ void __launch_bounds__(kSortThreads) k_sort_fused(
+    const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, int64_t n, int shift,
+    int bits, int tiles, const uint32_t* __restrict__ dhist, uint32_t* rows, int next_shift,
+    int next_bits, uint32_t* dhist_next, uint32_t* ticket, uint32_t* err,
+    uint32_t* __restrict__ kout, uint32_t* __restrict__ vout) {
+  __shared__ uint32_t nh[kSortMaxDigits];  // this tile's histogram of the NEXT pass's digit
+  __shared__ uint32_t cnt[kSortWaves][kSortMaxDigits];
+  __shared__ uint32_t ltot[kSortMaxDigits];
+  __shared__ uint32_t lexc[kSortMaxDigits];
+  __shared__ uint32_t gpre[kSortMaxDigits];
+  __shared__ uint32_t tpre[4][kSortMaxDigits];  // counts of the preceding tiles (four groups)
+  __shared__ uint32_t sk[kSortTile], sv[kSortTile];
+  __shared__ uint32_t s_tile;
+  const int nd = 1 << bits;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  for (int i = threadIdx.x; i < kSortWaves * kSortMaxDigits; i += kSortThreads)
+    (&cnt[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < kSortMaxDigits; i += kSortThreads) nh[i] = 0;
+  __syncthreads();
+  const int tile = (int)s_tile;
+  const int64_t tile0 = (int64_t)tile * kSortTile;
+  const int64_t base = tile0 + (int64_t)w * (64 * kSortItems);
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const int64_t i = base + r * 64 + lane;
+    const bool valid = i < n;
+    key[r] = valid ? kin[i] : 0u;
+    val[r] = valid ? (vin ? vin[i] : (uint32_t)i) : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const bool valid = base + r * 64 + lane < n;
+    const uint32_t d = (key[r] >> shift) & (uint32_t)(nd - 1);
+    unsigned long long peers = __ballot(valid);
+    for (int b = 0; b < bits; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    if (valid) {
+      const uint32_t prev = cnt[w][d];
+      rank[r] = prev + (uint32_t)__popcll(peers & lt);
+      if ((peers & lt) == 0) cnt[w][d] = prev + (uint32_t)__popcll(peers);
+    }
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < nd; d += kSortThreads) {
+    uint32_t run = 0;
+#pragma unroll
+    for (int ww = 0; ww < kSortWaves; ++ww) {
+      const uint32_t c = cnt[ww][d];
+      cnt[ww][d] = run;
+      run += c;
+    }
+    ltot[d] = run;
+    // publish this tile's digit count. Every word validates itself (kRowReady), so no fence is
+    // needed: an agent-scope fence on this chip writes back / invalidates a whole XCD L2, which
+    // costs far more than the sort itself
+    __hip_atomic_store(&rows[(size_t)tile * kSortMaxDigits + d], run | kRowReady, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (w == 0) wave_excl_scan_256(ltot, lexc, nd, lane);
+  if (w == 1) wave_excl_scan_256(dhist, gpre, nd, lane);
+  // digit totals of the next pass (its kernel reads them): done here, after publishing, so the
+  // tiles behind this one are not kept waiting
+  if (next_bits > 0) {
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+      if (base + r * 64 + lane < n)
+        atomicAdd(&nh[(key[r] >> next_shift) & (uint32_t)((1 << next_bits) - 1)], 1u);
+  }
+  // counts of the tiles before this one (smaller tickets: all of them are running and publish
+  // before they wait for anything). Four groups of 128 threads split the tiles; a thread reads
+  // two digits per 8-byte load, eight loads in flight.
+  {
+    const int grp = threadIdx.x >> 7, l2 = threadIdx.x & 127;
+    const int per = (tile + 3) >> 2;
+    const int t0 = min(tile, grp * per), t1 = min(tile, t0 + per);
+    uint32_t sum0 = 0, sum1 = 0;
+    if (2 * l2 < nd) {
+      const unsigned long long both = ((unsigned long long)kRowReady << 32) | kRowReady;
+      for (int tb = t0; tb < t1; tb += 8) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = min(tb + u, t1 - 1);
+          v[u] = __hip_atomic_load(
+              reinterpret_cast<const unsigned long long*>(&rows[(size_t)t * kSortMaxDigits]) + l2,
+              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (tb + u >= t1) break;
+          uint32_t spins = 0;
+          while ((v[u] & both) != both) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > kSpinLimit) {
+              atomicExch(err, 1u);
+              break;
+            }
+            v[u] = __hip_atomic_load(
+                reinterpret_cast<const unsigned long long*>(&rows[(size_t)(tb + u) * kSortMaxDigits]) + l2,
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          sum0 += (uint32_t)v[u] & ~kRowReady;
+          sum1 += (uint32_t)(v[u] >> 32) & ~kRowReady;
+        }
+      }
+    }
+    if (2 * l2 < kSortMaxDigits) {
+      tpre[grp][2 * l2] = sum0;
+      tpre[grp][2 * l2 + 1] = sum1;
+    }
+  }
+  __syncthreads();
+  if (next_bits > 0)
+    for (int i = threadIdx.x; i < (1 << next_bits); i += kSortThreads)
+      if (nh[i]) atomicAdd(&dhist_next[i], nh[i]);
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    if (base + r * 64 + lane < n) {
+      const uint32_t d = (key[r] >> shift) & (uint32_t)(nd - 1);
+      const uint32_t lp = lexc[d] + cnt[w][d] + rank[r];
+      sk[lp] = key[r];
+      sv[lp] = val[r];
+    }
+  }
+  __syncthreads();
+  const int count = (int)min((int64_t)kSortTile, n - tile0);
+  for (int j = threadIdx.x; j < count; j += kSortThreads) {
+    const uint32_t k = sk[j];
+    const uint32_t d = (k >> shift) & (uint32_t)(nd - 1);
+    const uint32_t pos = gpre[d] + tpre[0][d] + tpre[1][d] + tpre[2][d] + tpre[3][d] +
+                         ((uint32_t)j - lexc[d]);
+    kout[pos] = k;
+    vout[pos] = sv[j];
+  }
+}
+
+static uint32_t* g_sort_err = nullptr;  // device word of the last fused sort (debug aid)
+
+static bool fused_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MONO_SORT_FUSED");
+    on = e ? atoi(e) : 1;
+  }
+  return on != 0;
+}
+
 size_t sort_pairs_tmp_bytes(size_t n, int end_bit) {
   const size_t n_al = (n + 63) & ~(size_t)63;
   const size_t tiles = (n + kSortTile - 1) / kSortTile;
@@ -188,6 +388,10 @@ size_t sort_pairs_tmp_bytes(size_t n, int end_bit) {
   size_t b = 256 + kSortMaxDigits * sizeof(uint32_t);                       // digit totals
   b += ((tiles * kSortMaxDigits * sizeof(uint32_t)) + 255) & ~(size_t)255;  // tile histograms
   if (passes > 1) b += 2 * n_al * sizeof(uint32_t);                         // ping-pong buffer
+  // fused passes: digit histograms, flags, tickets, error word, per-pass tile rows
+  if (tiles <= (size_t)kFusedMaxTiles && passes <= kFusedMaxPasses)
+    b += 256 + kFusedMaxPasses * (kSortMaxDigits + kFusedMaxTiles + 16) * sizeof(uint32_t) +
+         (size_t)passes * tiles * kSortMaxDigits * sizeof(uint32_t);
   return b;
 }
 
@@ -209,6 +413,48 @@ int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uin
   p += (((size_t)tiles * kSortMaxDigits * sizeof(uint32_t)) + 255) & ~(size_t)255;
   uint32_t* tk = (uint32_t*)p;
   uint32_t* tv = tk + n_al;
+  if (fused_enabled() && tiles <= kFusedMaxTiles && passes <= kFusedMaxPasses) {
+    char* q = (char*)(tv + (passes > 1 ? n_al : 0));
+    if (passes <= 1) q = (char*)tk;
+    q = (char*)(((uintptr_t)q + 255) & ~(uintptr_t)255);
+    uint32_t* dhist = (uint32_t*)q;                                   // [passes][256]
+    uint32_t* flags = dhist + kFusedMaxPasses * kSortMaxDigits;       // [passes][kFusedMaxTiles]
+    uint32_t* ctl = flags + kFusedMaxPasses * kFusedMaxTiles;         // tickets [4], err
+    uint32_t* rows = ctl + 16 * kFusedMaxPasses;                      // [passes][tiles][256]
+    const size_t zero_bytes = (size_t)((char*)rows - (char*)dhist) +
+                              (size_t)passes * tiles * kSortMaxDigits * sizeof(uint32_t);
+    MONO_HIP(hipMemsetAsync(dhist, 0, zero_bytes, st));
+    FusedPass fp{};
+    fp.passes = passes;
+    int sh = 0;
+    for (int ps = 0; ps < passes; ++ps) {
+      const int left = passes - ps;
+      fp.shift[ps] = sh;
+      fp.bits[ps] = (end_bit - sh + left - 1) / left;
+      sh += fp.bits[ps];
+    }
+    hipLaunchKernelGGL(k_sort_ghist, dim3(tiles), dim3(kSortThreads), 0, st, kin, (int64_t)n,
+                       fp.shift[0], fp.bits[0], dhist);
+    const uint32_t* src_k = kin;
+    const uint32_t* src_v = vin;
+    for (int ps = 0; ps < passes; ++ps) {
+      const bool to_out = ((passes - 1 - ps) & 1) == 0;
+      uint32_t* dst_k = to_out ? kout : tk;
+      uint32_t* dst_v = to_out ? vout : tv;
+      hipLaunchKernelGGL(k_sort_fused, dim3(tiles), dim3(kSortThreads), 0, st, src_k, src_v,
+                         (int64_t)n, fp.shift[ps], fp.bits[ps], tiles,
+                         dhist + ps * kSortMaxDigits,
+                         rows + (size_t)ps * tiles * kSortMaxDigits,
+                         ps + 1 < passes ? fp.shift[ps + 1] : 0, ps + 1 < passes ? fp.bits[ps + 1] : 0,
+                         dhist + (ps + 1 < passes ? ps + 1 : ps) * kSortMaxDigits, ctl + ps,
+                         ctl + kFusedMaxPasses, dst_k, dst_v);
+      src_k = dst_k;
+      src_v = dst_v;
+    }
+    g_sort_err = ctl + kFusedMaxPasses;
+    MONO_HIP(hipGetLastError());
+    return 0;
+  }
   // even split of the key bits over the passes (29 bits -> 8 + 7 + 7 + 7)
   int shift = 0;
   const uint32_t* src_k = kin;
@@ -235,3 +481,12 @@ int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uin
 }
 
 }  // namespace mono
+
+extern "C" int mono_debug_sort_error(void) {
+  if (!mono::g_sort_err) return 0;
+  uint32_t v = 0;
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(&v, mono::g_sort_err, 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return (int)v;
+}

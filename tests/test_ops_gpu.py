@@ -266,3 +266,30 @@ def test_filter_random_counts_vs_oracle(ops):
     assert np.array_equal(got, exp), step
     q = rng.choice(pool, 500)
     assert np.array_equal(f.get(T(q, torch.int64)).cpu().numpy(), o.get(q))
+
+
+def test_sort_paths_small_fused_and_large_three_kernel():
+  """sort.hip has two paths: one fused kernel per pass up to 512 tiles (4.19 M pairs) and
+  hist / scan / scatter kernels beyond. fused_reorder_by_indices goes through the sort with
+  n pairs: both sides of the threshold must give the reference's first-occurrence order."""
+  import ctypes as C
+  import torch
+  from monolith_amd import _lib
+  from monolith_amd import distribution_ops as dops
+  for n in (512 * 8192 - 3, 512 * 8192, 512 * 8192 + 1, 5_000_000):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(n)
+    ids = torch.randint(0, 3_000_000, (n,), device="cuda", generator=g)
+    out, shard_sizes, sss, offsets = dops.fused_reorder_by_indices([ids], 4, [1])
+    out = out.cpu().numpy()
+    ref = ids.cpu().numpy()
+    uniq, first = np.unique(ref, return_index=True)
+    order = uniq[np.argsort(first, kind="stable")]           # first-occurrence order
+    exp = np.concatenate([order[order % 4 == s] for s in range(4)])
+    assert np.array_equal(out, exp)
+    assert np.asarray(shard_sizes).tolist() == [int((order % 4 == s).sum()) for s in range(4)]
+    # offsets (dim 1) index the unique list
+    assert np.array_equal(exp[offsets[0].cpu().numpy()], ref)
+  fn = _lib.lib.mono_debug_sort_error
+  fn.restype = C.c_int
+  assert fn() == 0
