@@ -101,8 +101,8 @@ int mono_filter_import_split(void* filter, int split, const uint16_t* h_cells, i
 int mono_filter_set_state(void* filter, int64_t head, int64_t head_increment, int64_t failure_count,
                           void* stream);
 
-/* Debug aid without a counterpart in the reference: 1 if a workgroup of the most recent fused
- * radix-sort pass (csrc/sort.hip) gave up waiting for its predecessors, 0 otherwise, -1 on a HIP
+/* Debug aid without a counterpart in the reference: 1 if a workgroup of any fused radix-sort
+ * pass of this process (csrc/sort.hip) ever gave up waiting for its predecessors, 0 otherwise, -1 on a HIP
  * error. Synchronises the device. */
 int mono_debug_sort_error(void);
 

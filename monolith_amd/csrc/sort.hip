@@ -5,8 +5,9 @@
 // 1..29 key bits. At that size a general-purpose library sort is launch-bound (buffer fills and
 // look-back state between passes). Two paths, both 8-bit digits over 8192-element tiles:
 //
-// up to 512 tiles (4.19 M pairs: every sort of the headline workload) — ONE kernel per pass:
-//   k_sort_ghist    digit totals of the first pass
+// up to 512 tiles (4.19 M pairs: every sort of the headline workload) — pass 0 as below (its
+// hist kernel also zeroes the scratch of the later passes, its scatter kernel accumulates pass
+// 1's digit totals), then ONE kernel per pass:
 //   k_sort_fused    ranks its tile, publishes the tile's digit counts as self-validating words
 //                   (count | ready bit: no fence, an agent-scope fence here writes back a whole
 //                   XCD L2), sums the counts of the tiles before it (tile numbers come from an
@@ -40,9 +41,16 @@ constexpr int kSortMaxDigits = 1 << kSortMaxBits;
 
 __global__ void __launch_bounds__(kSortThreads) k_sort_hist(const uint32_t* __restrict__ keys,
                                                             int64_t n, int shift, int bits,
-                                                            uint32_t* __restrict__ tile_hist) {
+                                                            uint32_t* __restrict__ tile_hist,
+                                                            uint32_t* __restrict__ zero_base,
+                                                            int64_t zero_words) {
   __shared__ uint32_t h[kSortMaxDigits];
   const int nd = 1 << bits;
+  // the fused passes that follow need their scratch zeroed: done here, one slice per workgroup,
+  // instead of a memset between the kernels
+  for (int64_t i = (int64_t)blockIdx.x * kSortThreads + threadIdx.x; i < zero_words;
+       i += (int64_t)gridDim.x * kSortThreads)
+    zero_base[i] = 0u;
   for (int d = threadIdx.x; d < nd; d += kSortThreads) h[d] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kSortTile;
@@ -112,7 +120,9 @@ __device__ __forceinline__ void wave_excl_scan_256(const uint32_t* in, uint32_t*
 __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
     const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, int64_t n, int shift,
     int bits, const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ dtot,
-    uint32_t* __restrict__ kout, uint32_t* __restrict__ vout) {
+    uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int next_shift, int next_bits,
+    uint32_t* dhist_next) {
+  __shared__ uint32_t nh[kSortMaxDigits];  // next pass's digit histogram of this tile (optional)
   __shared__ uint32_t cnt[kSortWaves][kSortMaxDigits];
   __shared__ uint32_t ltot[kSortMaxDigits];   // elements of this tile per digit
   __shared__ uint32_t lexc[kSortMaxDigits];   // ... exclusive scan = start of the digit's run
@@ -122,6 +132,7 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < kSortWaves * kSortMaxDigits; i += kSortThreads)
     (&cnt[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < kSortMaxDigits; i += kSortThreads) nh[i] = 0;
   __syncthreads();
   const int64_t tile0 = (int64_t)blockIdx.x * kSortTile;
   const int64_t base = tile0 + (int64_t)w * (64 * kSortItems);
@@ -151,7 +162,16 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
       if ((peers & lt) == 0) cnt[w][d] = prev + (uint32_t)__popcll(peers);
     }
   }
+  if (next_bits > 0) {
+#pragma unroll
+    for (int r = 0; r < kSortItems; ++r)
+      if (base + r * 64 + lane < n)
+        atomicAdd(&nh[(key[r] >> next_shift) & (uint32_t)((1 << next_bits) - 1)], 1u);
+  }
   __syncthreads();
+  if (next_bits > 0)
+    for (int i = threadIdx.x; i < (1 << next_bits); i += kSortThreads)
+      if (nh[i]) atomicAdd(&dhist_next[i], nh[i]);
   // per digit: start of every wave's share inside the digit's run, and the tile total
   for (int d = threadIdx.x; d < nd; d += kSortThreads) {
     uint32_t run = 0;
@@ -193,8 +213,8 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
 
 // ------------------------------------------------------------------------------ fused passes
 // For up to kFusedMaxTiles tiles one kernel per pass replaces hist + scan + scatter ("onesweep"
-// without the chained scan): the digit totals of ALL passes come from one upfront histogram of
-// the input keys; inside a pass every workgroup ranks its tile, publishes the tile's digit counts
+// without the chained scan): the digit totals of a pass are accumulated by the pass before it;
+// inside a pass every workgroup ranks its tile, publishes the tile's digit counts
 // and a ready flag, waits for the flags of the tiles before it, and sums their counts itself.
 // Tile numbers are handed out by an atomic ticket, so every tile a workgroup waits for has
 // already started and publishes before it waits on anything: the wait always ends. The spin is
@@ -209,23 +229,6 @@ struct FusedPass {
   int bits[kFusedMaxPasses];
   int passes;
 };
-
-__global__ void __launch_bounds__(kSortThreads) k_sort_ghist(const uint32_t* __restrict__ keys,
-                                                             int64_t n, int shift, int bits,
-                                                             uint32_t* __restrict__ dhist) {
-  __shared__ uint32_t h[kSortMaxDigits];
-  for (int i = threadIdx.x; i < kSortMaxDigits; i += kSortThreads) h[i] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kSortTile;
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    const int64_t i = base + r * kSortThreads + threadIdx.x;
-    if (i < n) atomicAdd(&h[(keys[i] >> shift) & (uint32_t)((1 << bits) - 1)], 1u);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < kSortMaxDigits; i += kSortThreads)
-    if (h[i]) atomicAdd(&dhist[i], h[i]);
-}
 
 __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
     const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, int64_t n, int shift,
@@ -370,7 +373,7 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
   }
 }
 
-static uint32_t* g_sort_err = nullptr;  // device word of the last fused sort (debug aid)
+static uint32_t* g_sort_err = nullptr;  // sticky device word, allocated once per process
 
 static bool fused_enabled() {
   static int on = -1;
@@ -390,7 +393,7 @@ size_t sort_pairs_tmp_bytes(size_t n, int end_bit) {
   if (passes > 1) b += 2 * n_al * sizeof(uint32_t);                         // ping-pong buffer
   // fused passes: digit histograms, flags, tickets, error word, per-pass tile rows
   if (tiles <= (size_t)kFusedMaxTiles && passes <= kFusedMaxPasses)
-    b += 256 + kFusedMaxPasses * (kSortMaxDigits + kFusedMaxTiles + 16) * sizeof(uint32_t) +
+    b += 256 + kFusedMaxPasses * (kSortMaxDigits + 16) * sizeof(uint32_t) +
          (size_t)passes * tiles * kSortMaxDigits * sizeof(uint32_t);
   return b;
 }
@@ -413,17 +416,17 @@ int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uin
   p += (((size_t)tiles * kSortMaxDigits * sizeof(uint32_t)) + 255) & ~(size_t)255;
   uint32_t* tk = (uint32_t*)p;
   uint32_t* tv = tk + n_al;
-  if (fused_enabled() && tiles <= kFusedMaxTiles && passes <= kFusedMaxPasses) {
-    char* q = (char*)(tv + (passes > 1 ? n_al : 0));
-    if (passes <= 1) q = (char*)tk;
+  if (fused_enabled() && passes >= 2 && tiles <= kFusedMaxTiles && passes <= kFusedMaxPasses) {
+    if (!g_sort_err) {  // first fused sort of the process
+      MONO_HIP(hipMalloc((void**)&g_sort_err, 256));
+      MONO_HIP(hipMemsetAsync(g_sort_err, 0, 256, st));
+    }
+    char* q = (char*)(tv + n_al);
     q = (char*)(((uintptr_t)q + 255) & ~(uintptr_t)255);
     uint32_t* dhist = (uint32_t*)q;                                   // [passes][256]
-    uint32_t* flags = dhist + kFusedMaxPasses * kSortMaxDigits;       // [passes][kFusedMaxTiles]
-    uint32_t* ctl = flags + kFusedMaxPasses * kFusedMaxTiles;         // tickets [4], err
+    uint32_t* ctl = dhist + kFusedMaxPasses * kSortMaxDigits;         // tickets [4], err
     uint32_t* rows = ctl + 16 * kFusedMaxPasses;                      // [passes][tiles][256]
-    const size_t zero_bytes = (size_t)((char*)rows - (char*)dhist) +
-                              (size_t)passes * tiles * kSortMaxDigits * sizeof(uint32_t);
-    MONO_HIP(hipMemsetAsync(dhist, 0, zero_bytes, st));
+    const int64_t zero_words = (int64_t)(rows - dhist) + (int64_t)passes * tiles * kSortMaxDigits;
     FusedPass fp{};
     fp.passes = passes;
     int sh = 0;
@@ -433,25 +436,36 @@ int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uin
       fp.bits[ps] = (end_bit - sh + left - 1) / left;
       sh += fp.bits[ps];
     }
-    hipLaunchKernelGGL(k_sort_ghist, dim3(tiles), dim3(kSortThreads), 0, st, kin, (int64_t)n,
-                       fp.shift[0], fp.bits[0], dhist);
-    const uint32_t* src_k = kin;
-    const uint32_t* src_v = vin;
-    for (int ps = 0; ps < passes; ++ps) {
+    // pass 0: its tile histograms exist before any tile is ranked, so the plain kernels are the
+    // cheapest form; the hist kernel also zeroes the scratch of the fused passes and the scatter
+    // kernel accumulates pass 1's digit totals
+    const bool out0 = ((passes - 1) & 1) == 0;
+    uint32_t* d0k = out0 ? kout : tk;
+    uint32_t* d0v = out0 ? vout : tv;
+    hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(kSortThreads), 0, st, kin, (int64_t)n,
+                       fp.shift[0], fp.bits[0], thist, dhist, zero_words);
+    hipLaunchKernelGGL(k_sort_scan, dim3(((1 << fp.bits[0]) + 31) / 32), dim3(1024), 0, st, thist,
+                       dtot, tiles, fp.bits[0]);
+    hipLaunchKernelGGL(k_sort_scatter, dim3(tiles), dim3(kSortThreads), 0, st, kin, vin, (int64_t)n,
+                       fp.shift[0], fp.bits[0], thist, dtot, d0k, d0v, fp.shift[1], fp.bits[1],
+                       dhist + kSortMaxDigits);
+    const uint32_t* src_k = d0k;
+    const uint32_t* src_v = d0v;
+    for (int ps = 1; ps < passes; ++ps) {
       const bool to_out = ((passes - 1 - ps) & 1) == 0;
       uint32_t* dst_k = to_out ? kout : tk;
       uint32_t* dst_v = to_out ? vout : tv;
+      const bool more = ps + 1 < passes;
       hipLaunchKernelGGL(k_sort_fused, dim3(tiles), dim3(kSortThreads), 0, st, src_k, src_v,
                          (int64_t)n, fp.shift[ps], fp.bits[ps], tiles,
                          dhist + ps * kSortMaxDigits,
                          rows + (size_t)ps * tiles * kSortMaxDigits,
-                         ps + 1 < passes ? fp.shift[ps + 1] : 0, ps + 1 < passes ? fp.bits[ps + 1] : 0,
-                         dhist + (ps + 1 < passes ? ps + 1 : ps) * kSortMaxDigits, ctl + ps,
-                         ctl + kFusedMaxPasses, dst_k, dst_v);
+                         more ? fp.shift[ps + 1] : 0, more ? fp.bits[ps + 1] : 0,
+                         dhist + (more ? ps + 1 : ps) * kSortMaxDigits, ctl + ps,
+                         g_sort_err, dst_k, dst_v);
       src_k = dst_k;
       src_v = dst_v;
     }
-    g_sort_err = ctl + kFusedMaxPasses;
     MONO_HIP(hipGetLastError());
     return 0;
   }
@@ -467,11 +481,12 @@ int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uin
     uint32_t* dst_k = to_out ? kout : tk;
     uint32_t* dst_v = to_out ? vout : tv;
     hipLaunchKernelGGL(k_sort_hist, dim3(tiles), dim3(kSortThreads), 0, st, src_k, (int64_t)n,
-                       shift, bits, thist);
+                       shift, bits, thist, (uint32_t*)nullptr, (int64_t)0);
     hipLaunchKernelGGL(k_sort_scan, dim3(((1 << bits) + 31) / 32), dim3(1024), 0, st, thist, dtot,
                        tiles, bits);
     hipLaunchKernelGGL(k_sort_scatter, dim3(tiles), dim3(kSortThreads), 0, st, src_k, src_v,
-                       (int64_t)n, shift, bits, thist, dtot, dst_k, dst_v);
+                       (int64_t)n, shift, bits, thist, dtot, dst_k, dst_v, 0, 0,
+                       (uint32_t*)nullptr);
     src_k = dst_k;
     src_v = dst_v;
     shift += bits;
