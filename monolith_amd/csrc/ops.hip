@@ -262,7 +262,10 @@ __device__ inline int64_t floormod_dev(int64_t a, int64_t b) {
 }
 
 // Pass 1: per-slot dedup set in HBM (open addressing, 64-bit CAS); every cell remembers the
-// smallest global occurrence index that hit it = the first occurrence.
+// smallest global occurrence index that hit it = the first occurrence. A cell is 16 bytes
+// {int64 key; uint32 first; pad}: key probe and first-occurrence update touch ONE line (as two
+// arrays the insert was bound by random line requests). hkeys / hfirst point into the same
+// array: key of cell c = hkeys[2 c], first = hfirst[4 c].
 __global__ void __launch_bounds__(256) k_reorder_insert(ReorderArgs a, const SlotMeta* sm,
                                                         int64_t* hkeys, uint32_t* hfirst,
                                                         uint32_t* hcell, int phase) {
@@ -284,7 +287,7 @@ __global__ void __launch_bounds__(256) k_reorder_insert(ReorderArgs a, const Slo
     } else {
       uint64_t p = mix64((uint64_t)key) & s.hash_mask;
       for (;;) {
-        int64_t* kp = hkeys + s.hash_base + (int64_t)p;
+        int64_t* kp = hkeys + 2 * (s.hash_base + (int64_t)p);
         int64_t cur = *kp;
         if (cur == -1) {
           cur = (int64_t)atomicCAS(reinterpret_cast<unsigned long long*>(kp),
@@ -297,9 +300,14 @@ __global__ void __launch_bounds__(256) k_reorder_insert(ReorderArgs a, const Slo
       cell = s.hash_base + (int64_t)p;
     }
     hcell[g] = (uint32_t)cell;
-    // hfirst only decreases: an occurrence that already sees a smaller index has nothing to
-    // add, which spares the hot keys tens of thousands of serialised atomics on one word
-    if (__builtin_nontemporal_load(&hfirst[cell]) > (uint32_t)g) atomicMin(&hfirst[cell], (uint32_t)g);
+    // first only decreases: an occurrence that already sees a smaller index has nothing to add,
+    // which spares the hot keys tens of thousands of serialised atomics on one word. A plain
+    // (cacheable) load: the word shares the line the key probe just fetched, and a stale value
+    // can only be LARGER than the current one, i.e. cause a redundant atomic, never a missed one.
+    // (Device-scope atomics on random words run at ~20 G/s on this part; a load that goes to
+    // memory for the guard costs as much as the atomic it saves.)
+    uint32_t* fp = hfirst + 4 * (size_t)cell;
+    if (*fp > (uint32_t)g) atomicMin(fp, (uint32_t)g);
   }
 }
 
@@ -312,7 +320,7 @@ __global__ void __launch_bounds__(256) k_reorder_keys(ReorderArgs a, const SlotM
        g += (int64_t)gridDim.x * blockDim.x) {
     const int m = find_slot_of(sm, a.M, g);
     uint32_t key = (uint32_t)(a.N * a.M);
-    if (hfirst[hcell[g]] == (uint32_t)g) {
+    if (hfirst[4 * (size_t)hcell[g]] == (uint32_t)g) {
       const int64_t id = sm[m].ids[g - sm[m].base];
       // distribution_ops.py:255-272
       const int shard = a.shard_rule == 1 ? (int)(1 + floormod_dev(id, a.N - 1))
@@ -354,7 +362,7 @@ __global__ void __launch_bounds__(256) k_reorder_emit(ReorderArgs a, const SlotM
     const uint32_t g = sidx[r];
     const SlotMeta& s = sm[key % a.M];
     out_ids[r] = s.ids[(int64_t)g - s.base];
-    hfirst[hcell[g]] = (uint32_t)emb_off[r];  // the cell now carries the embedding offset
+    hfirst[4 * (size_t)hcell[g]] = (uint32_t)emb_off[r];  // the cell now carries the embedding offset
   }
 }
 
@@ -364,7 +372,7 @@ __global__ void __launch_bounds__(256) k_reorder_offsets(ReorderArgs a, const Sl
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total;
        g += (int64_t)gridDim.x * blockDim.x) {
     const int m = find_slot_of(sm, a.M, g);
-    sm[m].out_off[g - sm[m].base] = (int32_t)hfirst[hcell[g]];
+    sm[m].out_off[g - sm[m].base] = (int32_t)hfirst[4 * (size_t)hcell[g]];
   }
 }
 
@@ -388,7 +396,7 @@ __global__ void __launch_bounds__(256) k_shard_keys(ShardArgs a, const SlotMeta*
        g += (int64_t)gridDim.x * blockDim.x) {
     const int m = find_slot_of(sm, a.M, g);
     uint32_t key = (uint32_t)a.n_out;
-    if (!a.unique || hfirst[hcell[g]] == (uint32_t)g) {
+    if (!a.unique || hfirst[4 * (size_t)hcell[g]] == (uint32_t)g) {
       const int64_t id = sm[m].ids[g - sm[m].base];
       key = (uint32_t)a.out_index[m * a.ps_num + shard_of_fid(id, a.ps_num)];
     }
@@ -417,7 +425,7 @@ __global__ void __launch_bounds__(256) k_shard_emit(ShardArgs a, const SlotMeta*
     const int m = find_slot_of(sm, a.M, g);
     fid_list[r] = sm[m].ids[(int64_t)g - sm[m].base];
     const uint32_t idx = (uint32_t)(r - start[key]);
-    if (a.unique) hfirst[hcell[g]] = idx;  // the dedup cell now carries the list index
+    if (a.unique) hfirst[4 * (size_t)hcell[g]] = idx;  // the dedup cell now carries the list index
     else fid_offset[g] = ((uint64_t)key << 32) | idx;
   }
 }
@@ -431,7 +439,7 @@ __global__ void __launch_bounds__(256) k_shard_offsets(ShardArgs a, const SlotMe
     const int m = find_slot_of(sm, a.M, g);
     const int64_t id = sm[m].ids[g - sm[m].base];
     const uint32_t key = (uint32_t)a.out_index[m * a.ps_num + shard_of_fid(id, a.ps_num)];
-    fid_offset[g] = ((uint64_t)key << 32) | hfirst[hcell[g]];
+    fid_offset[g] = ((uint64_t)key << 32) | hfirst[4 * (size_t)hcell[g]];
   }
 }
 
@@ -671,8 +679,8 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   size_t bytes = 256 + sizeof(SlotMeta) * M + 64;
   const size_t off_meta = 256;
   const size_t off_hkeys = (off_meta + sizeof(SlotMeta) * M + 63) & ~(size_t)63;
-  const size_t off_hfirst = off_hkeys + c_al * 8;
-  const size_t off_hcell = off_hfirst + c_al * 4;
+  const size_t off_hfirst = off_hkeys + 8;  // interleaved 16-byte cells
+  const size_t off_hcell = off_hkeys + c_al * 16;
   const size_t off_skey = off_hcell + t_al * 4;
   const size_t off_sidx = off_skey + t_al * 4;
   const size_t off_skey2 = off_sidx + t_al * 4;
@@ -695,8 +703,7 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   int32_t* scan = (int32_t*)(base + off_scan);
   int32_t* hist = (int32_t*)(base + off_hist);
   MONO_HIP(hipMemcpyAsync(d_sm, sm.data(), sizeof(SlotMeta) * M, hipMemcpyHostToDevice, st));
-  MONO_HIP(hipMemsetAsync(hkeys, 0xFF, c_al * 8, st));
-  MONO_HIP(hipMemsetAsync(hfirst, 0xFF, c_al * 4, st));
+  MONO_HIP(hipMemsetAsync(hkeys, 0xFF, c_al * 16, st));
   MONO_HIP(hipMemsetAsync(hist, 0, hist_al * 4, st));
   ReorderArgs a{M, N, shard_rule, total};
   const dim3 grid(grid_for(total, 256)), blk(256);
@@ -766,8 +773,8 @@ int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* 
   const size_t off_rm = (off_sm + sizeof(SlotMeta) * M + 63) & ~(size_t)63;
   const size_t off_oi = (off_rm + sizeof(RunMeta) * M + 63) & ~(size_t)63;
   const size_t off_hkeys = (off_oi + (size_t)M * ps_num * 4 + 63) & ~(size_t)63;
-  const size_t off_hfirst = off_hkeys + c_al * 8;
-  const size_t off_hcell = off_hfirst + c_al * 4;
+  const size_t off_hfirst = off_hkeys + 8;  // interleaved 16-byte cells
+  const size_t off_hcell = off_hkeys + c_al * 16;
   const size_t off_skey = off_hcell + (unique ? t_al * 4 : 0);
   const size_t off_skey2 = off_skey + t_al * 4;
   const size_t off_sidx2 = off_skey2 + t_al * 4;
@@ -801,8 +808,7 @@ int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* 
   const dim3 grid(grid_for(total, 256));
   ShardArgs a{M, ps_num, n_out, unique ? 1 : 0, total, d_oi};
   if (unique) {
-    MONO_HIP(hipMemsetAsync(hkeys, 0xFF, c_al * 8, st));
-    MONO_HIP(hipMemsetAsync(hfirst, 0xFF, c_al * 4, st));
+    MONO_HIP(hipMemsetAsync(hkeys, 0xFF, c_al * 16, st));
     ReorderArgs ra{M, ps_num, 0, total};
     hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hkeys, hfirst, hcell, 0);
     hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hkeys, hfirst, hcell, 1);
