@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t
                                                        uint32_t* __restrict__ zero4) {
   // the apply phase's four queue counters are cleared here: a separate memset costs ~10 us of
   // stream bubble between the sort and k_classify
-  if (zero4 && blockIdx.x == 0 && threadIdx.x < 4) zero4[threadIdx.x] = 0;
+  if (zero4 && blockIdx.x == 0 && threadIdx.x < 8) zero4[threadIdx.x] = 0;
   const int sub = lane_sub(), gshift = lane_gshift();
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
   for (int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8) * kIlp; i0 < n;
@@ -362,6 +362,7 @@ struct ApplyArgs {
   int assign_add_semantics;  // filter gate of the per-id AssignAdd loop (bridge :186-209)
   struct LongSeg* queue;     // segments longer than kLongSeg, drained by k_apply_long
   uint32_t* qcount;          // [0] queue entries [1] compacted heads [2] split keys [3] partial rows
+                             // [4] next queue entry to hand out (k_apply_long)
   struct SplitSeg* cqueue;   // keys whose segment was cut into chunks, finished by k_combine
   float* partials;           // [partial row][dim] chunk sums of the split keys
   int chunk;                 // occurrences above which a key is split (kChunk)
@@ -485,8 +486,10 @@ __device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t e
 // Write path, step 2: one 8-lane sub-group per distinct key walks that key's occurrences in
 // input order (the sort is stable) with the row chunk held in registers, then stores row + ts.
 // B3/B4: bridge :156-313, cuckoo_embedding_hash_table.cc:174-216, entry_accessor.cc:149-171.
+// 8 waves / SIMD (64 VGPRs, a 36-byte spill): the kernel is bound by memory latency x resident
+// sub-groups, and the extra wave is worth more than the spill costs (7.83 -> 8.01 G).
 template <int V, int OPTK>
-__global__ void __launch_bounds__(256) k_apply(TableDev t, ApplyArgs a) {
+__global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
   const int sub = lane_sub(), gshift = lane_gshift();
   int64_t j = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
   if (j >= a.n) return;
@@ -780,7 +783,15 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
   // The consumer wave is a lone dependent chain; when this kernel shares CUs with k_apply its
   // issue slots must not be arbitrated away, so it runs at raised wave priority.
   if (!loader) __builtin_amdgcn_s_setprio(3);
-  for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+  // Entries differ in length by 40x: they are handed out one at a time (a static stride left
+  // some workgroups with two 4096-row chunks while others idled).
+  __shared__ uint32_t s_qi;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) s_qi = atomicAdd(&a.qcount[4], 1u);
+    __syncthreads();
+    const uint32_t qi = s_qi;
+    if (qi >= nq) break;
     const LongSeg ls = a.queue[qi];
     float* row = t.rows + (uint64_t)ls.slot * R;
     const int64_t ntiles = (ls.end - ls.first + rpt - 1) / rpt;
@@ -1321,7 +1332,7 @@ static int queue_setup(ApplyArgs* a, char* q_base, int64_t n, int dim, uint4** h
   a->cqueue = (SplitSeg*)(q_base + 256 + q.lq);
   a->partials = (float*)(q_base + 256 + q.lq + q.cq);
   *heads = (uint4*)(q_base + 256 + q.lq + q.cq + q.pt);
-  if (!counters_cleared) MONO_HIP(hipMemsetAsync(a->qcount, 0, 4 * sizeof(uint32_t), st));
+  if (!counters_cleared) MONO_HIP(hipMemsetAsync(a->qcount, 0, 8 * sizeof(uint32_t), st));
   return 0;
 }
 
