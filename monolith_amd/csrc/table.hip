@@ -74,6 +74,14 @@ struct Table {
   int opt_tmpl = OPTK_SGD;  // kernel specialisation
   int vec = 1;              // floats per lane per access
   int64_t used_upper = 0;   // host upper bound of live + tombstones
+  // Slots the last mono_table_lookup resolved, position by position: the write call that
+  // follows on the same ids (forward lookup, backward update) reads them back instead of
+  // probing again. Valid while no key has moved or been removed (rehash / evict / clear reset
+  // cache_n); an insert never moves an existing key. A position whose id differs, or that
+  // missed in the lookup, probes as usual.
+  int64_t* cache_ids = nullptr;
+  uint32_t* cache_slots = nullptr;
+  int64_t cache_n = 0, cache_cap = 0;
   int64_t max_update_ts = 0;
   int32_t* slot_expire_dev = nullptr;
   Workspace ws;
@@ -244,7 +252,9 @@ __device__ __forceinline__ void vstore(float* p, const float (&r)[V]) {
 constexpr int kIlp = 4;
 template <int V>
 __global__ void __launch_bounds__(256) k_lookup(TableDev t, const int64_t* __restrict__ ids,
-                                                int64_t n, float* __restrict__ out) {
+                                                int64_t n, float* __restrict__ out,
+                                                int64_t* __restrict__ cache_ids,
+                                                uint32_t* __restrict__ cache_slots) {
   const int sub = lane_sub(), gshift = lane_gshift();
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
   const int D = t.dim;
@@ -262,6 +272,15 @@ __global__ void __launch_bounds__(256) k_lookup(TableDev t, const int64_t* __res
     }
 #pragma unroll
     for (int q = 0; q < kIlp; ++q) slot[q] = group_find_pre(t, key[q], b[q], k0[q], sub, gshift);
+    if (cache_ids && sub < kIlp && i0 + sub < n) {  // lane q of the sub-group records id q
+      int64_t ck = key[0];
+      uint32_t cs = slot[0];
+#pragma unroll
+      for (int q = 1; q < kIlp; ++q)
+        if (sub == q) { ck = key[q]; cs = slot[q]; }
+      cache_ids[i0 + sub] = ck;
+      cache_slots[i0 + sub] = cs;
+    }
     for (int e = sub * V; e < D; e += 8 * V) {
       float r[kIlp][V];
 #pragma unroll
@@ -290,12 +309,32 @@ __global__ void __launch_bounds__(256) k_contains(TableDev t, const int64_t* __r
   }
 }
 
+// Write path, step 0: positions the preceding lookup already resolved (same id at the same
+// position) take their slot from the cache, one thread per id, fully coalesced; the rest is
+// marked kPendingSlot for k_find_or_claim.
+constexpr uint32_t kPendingSlot = 0xFFFFFFFEu;
+__global__ void __launch_bounds__(256) k_slots_from_cache(const int64_t* __restrict__ ids, int64_t n,
+                                                          const int64_t* __restrict__ cache_ids,
+                                                          const uint32_t* __restrict__ cache_slots,
+                                                          int64_t cache_n,
+                                                          uint32_t* __restrict__ slot_out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t s = kPendingSlot;
+    if (i < cache_n && cache_ids[i] == ids[i]) {
+      const uint32_t c = cache_slots[i];
+      if (c != kNoSlot) s = c;
+    }
+    slot_out[i] = s;
+  }
+}
+
 // Write path, step 1 (no filter): resolve every occurrence to its slot, inserting + initialising
 // missing keys (cuckoo_embedding_hash_table.cc:284-291). Emits (slot, occurrence index) pairs.
 __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t* __restrict__ ids,
                                                        int64_t n, uint32_t* __restrict__ slot_out,
-                                                       uint32_t* __restrict__ idx_out,
-                                                       uint32_t* __restrict__ zero4) {
+                                                       uint32_t* __restrict__ zero4,
+                                                       int pending_only) {
   // the apply phase's four queue counters are cleared here: a separate memset costs ~10 us of
   // stream bubble between the sort and k_classify
   if (zero4 && blockIdx.x == 0 && threadIdx.x < 8) zero4[threadIdx.x] = 0;
@@ -307,16 +346,31 @@ __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t
     // is decided from them, anything else takes the claiming probe
     int64_t key[kIlp], k0[kIlp];
     uint64_t b[kIlp];
+    uint32_t cached[kIlp];  // slot k_slots_from_cache already resolved (pending_only)
+#pragma unroll
+    for (int q = 0; q < kIlp; ++q) cached[q] = kNoSlot;
+    if (pending_only) {
+      bool any = false;
+#pragma unroll
+      for (int q = 0; q < kIlp; ++q) {
+        if (i0 + q < n) {
+          const uint32_t sv = slot_out[i0 + q];
+          if (sv == kPendingSlot) any = true; else cached[q] = sv;
+        }
+      }
+      if (!any) continue;
+    }
 #pragma unroll
     for (int q = 0; q < kIlp; ++q) key[q] = i0 + q < n ? ids[i0 + q] : kEmpty;
 #pragma unroll
     for (int q = 0; q < kIlp; ++q) {
       b[q] = mix64((uint64_t)key[q]) & t.bucket_mask;
-      k0[q] = t.keys[b[q] * kBucket + sub];
+      k0[q] = cached[q] == kNoSlot ? t.keys[b[q] * kBucket + sub] : kEmpty;
     }
 #pragma unroll
     for (int q = 0; q < kIlp; ++q) {
       if (i0 + q >= n) continue;
+      if (cached[q] != kNoSlot) continue;  // its slot is in slot_out already
       const bool special = key[q] == kEmpty || key[q] == kTomb;
       uint32_t m = group_bits(!special && k0[q] == key[q], gshift);
       uint32_t slot;
@@ -333,10 +387,7 @@ __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t
           }
         }
       }
-      if (sub == 0) {
-        slot_out[i0 + q] = slot;
-        idx_out[i0 + q] = (uint32_t)(i0 + q);
-      }
+      if (sub == 0) slot_out[i0 + q] = slot;
     }
   }
 }
@@ -1152,6 +1203,7 @@ static int read_counters(Table* t, hipStream_t st, int64_t* live, int64_t* tombs
 
 // Rehash into a table of `new_cap` slots (drops tombstones). Peak memory = old + new arrays.
 static int rehash(Table* t, uint64_t new_cap, hipStream_t st) {
+  t->cache_n = 0;  // every key moves
   TableDev nw = t->d;
   nw.keys = nullptr; nw.ts = nullptr; nw.rows = nullptr; nw.special = nullptr; nw.counters = nullptr;
   MONO_TRY(alloc_arrays(&nw, new_cap));
@@ -1174,6 +1226,14 @@ static int rehash(Table* t, uint64_t new_cap, hipStream_t st) {
 }
 
 // Called before any launch that can insert up to `incoming` new keys.
+static bool slot_cache_enabled() {  // MONO_SLOT_CACHE=0 switches the lookup -> update hand-off off
+  static const bool on = [] {
+    const char* e = getenv("MONO_SLOT_CACHE");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
+
 static int ensure_room(Table* t, int64_t incoming, hipStream_t st) {
   const int64_t limit = (int64_t)(kMaxLoad * (double)t->d.cap);
   if (t->used_upper + incoming <= limit) {
@@ -1192,8 +1252,10 @@ static int ensure_room(Table* t, int64_t incoming, hipStream_t st) {
 }
 
 template <int V>
-static void launch_lookup(const Table* t, const int64_t* ids, int64_t n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(k_lookup<V>, dim3(grid_for(n, 32 * kIlp)), dim3(256), 0, st, t->d, ids, n, out);
+static void launch_lookup(const Table* t, const int64_t* ids, int64_t n, float* out, hipStream_t st,
+                          int64_t* cache_ids = nullptr, uint32_t* cache_slots = nullptr) {
+  hipLaunchKernelGGL(k_lookup<V>, dim3(grid_for(n, 32 * kIlp)), dim3(256), 0, st, t->d, ids, n, out,
+                     cache_ids, cache_slots);
 }
 
 template <int V, int OPTK>
@@ -1381,11 +1443,17 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
     uint32_t* slot_out = idx_in + n_al;
     uint32_t* idx_out = slot_out + n_al;
     void* tmp = idx_out + n_al;
+    const int cached = t->cache_n > 0 ? 1 : 0;
+    if (cached)
+      hipLaunchKernelGGL(k_slots_from_cache, dim3(grid_for(n, 1024)), dim3(256), 0, st, ids, n,
+                         t->cache_ids, t->cache_slots, t->cache_n, slot_in);
     hipLaunchKernelGGL(k_find_or_claim, dim3(grid_for(n, 32 * kIlp)), dim3(256), 0, st, t->d, ids, n,
-                       slot_in, idx_in, (uint32_t*)q_base);
+                       slot_in, (uint32_t*)q_base, cached);
     MONO_HIP(hipGetLastError());
     if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
-    MONO_TRY(sort_pairs_u32(slot_in, slot_out, idx_in, idx_out, (size_t)n, end_bit, tmp, tmp_bytes,
+    // values = input positions (the sort's identity default): no index array to write and read
+    (void)idx_in;
+    MONO_TRY(sort_pairs_u32(slot_in, slot_out, nullptr, idx_out, (size_t)n, end_bit, tmp, tmp_bytes,
                             st));
     a.skeys = slot_out;
     a.sidx = idx_out;
@@ -1544,6 +1612,8 @@ int mono_table_destroy(void* table) {
   Table* t = (Table*)table;
   free_arrays(&t->d);
   if (t->slot_expire_dev) (void)hipFree(t->slot_expire_dev);
+  if (t->cache_ids) (void)hipFree(t->cache_ids);
+  if (t->cache_slots) (void)hipFree(t->cache_slots);
   t->ws.release();
   for (int i = 0; i < 4; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
@@ -1583,9 +1653,24 @@ int mono_table_lookup(void* table, const int64_t* ids, int64_t n, float* out, vo
   Table* t = (Table*)table;
   hipStream_t st = (hipStream_t)stream;
   const bool aligned = ((uintptr_t)out & 15) == 0;
-  if (t->d.dim % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) launch_lookup<4>(t, ids, n, out, st);
-  else if (t->d.dim % 2 == 0 && t->d.row_floats % 2 == 0 && aligned) launch_lookup<2>(t, ids, n, out, st);
-  else launch_lookup<1>(t, ids, n, out, st);
+  if (slot_cache_enabled() && n < (int64_t)0xFFFFFFF0ll) {
+    if (n > t->cache_cap) {  // grows once per batch size; (re)allocation synchronises
+      if (t->cache_ids) (void)hipFree(t->cache_ids);
+      if (t->cache_slots) (void)hipFree(t->cache_slots);
+      t->cache_ids = nullptr; t->cache_slots = nullptr; t->cache_cap = 0; t->cache_n = 0;
+      MONO_HIP(hipMalloc((void**)&t->cache_ids, (size_t)n * sizeof(int64_t)));
+      MONO_HIP(hipMalloc((void**)&t->cache_slots, (size_t)n * sizeof(uint32_t)));
+      t->cache_cap = n;
+    }
+    t->cache_n = n;
+  } else {
+    t->cache_n = 0;
+  }
+  int64_t* ci = t->cache_n ? t->cache_ids : nullptr;
+  uint32_t* cs = t->cache_n ? t->cache_slots : nullptr;
+  if (t->d.dim % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) launch_lookup<4>(t, ids, n, out, st, ci, cs);
+  else if (t->d.dim % 2 == 0 && t->d.row_floats % 2 == 0 && aligned) launch_lookup<2>(t, ids, n, out, st, ci, cs);
+  else launch_lookup<1>(t, ids, n, out, st, ci, cs);
   MONO_HIP(hipGetLastError());
   return 0;
 }
@@ -1659,12 +1744,14 @@ int mono_table_clear(void* table, void* stream) {
   Table* t = (Table*)table;
   MONO_TRY(reset_arrays(&t->d, (hipStream_t)stream));
   t->used_upper = 0;
+  t->cache_n = 0;
   return 0;
 }
 
 int mono_table_evict(void* table, int64_t max_update_time, void* stream) {
   MONO_REQUIRE(table, "mono_table_evict: null table");
   Table* t = (Table*)table;
+  t->cache_n = 0;  // evicted slots may be claimed by other keys
   hipLaunchKernelGGL(k_evict, dim3(grid_for((int64_t)t->d.cap + 2, 256)), dim3(256), 0,
                      (hipStream_t)stream, t->d, max_update_time);
   MONO_HIP(hipGetLastError());

@@ -204,3 +204,69 @@ def test_filter_gate_closed_forms():
       _assert_same_state(o, h)
       probe = np.unique(ids)
       assert np.array_equal(of.get(probe), hf.get(torch.as_tensor(probe).cuda()).cpu().numpy())
+
+
+def test_lookup_slot_cache_hazards():
+  """mono_table_lookup remembers the slot of every position for the update that follows
+  (table.hip: cache_ids / cache_slots). Everything that could make those slots stale — other
+  ids in the update, ids overwritten in place, eviction, clear, growth (rehash), keys missing at
+  lookup time — must still give the oracle's result bit for bit."""
+  import torch
+  from tests import hip_backend, oracle_backend
+  cfg = {"segments": [{"dim": 8, "opt": "adagrad", "init": "uniform", "init_a": -0.1, "init_b": 0.1}],
+         "seed": 4, "default_expire_days": 1}
+  o, h = oracle_backend.make_table(cfg), hip_backend.make_table(cfg)
+  rng = np.random.Generator(np.random.PCG64(21))
+  day = 86400
+
+  def both(fn):
+    fn(o)
+    fn(h)
+
+  def check(probe):
+    assert np.array_equal(o.lookup(probe).view(np.uint32), h.lookup(probe).view(np.uint32))
+
+  n = 4000
+  ids = rng.integers(0, 3000, n).astype(np.int64)
+  g = rng.normal(0, 0.2, (n, 8)).astype(np.float32)
+  probe = np.arange(-10, 3100, dtype=np.int64)
+  # 1. plain forward / backward on the same ids; half of them unknown at lookup time
+  both(lambda t: t.lookup(ids))
+  both(lambda t: t.apply_gradients(ids, g, [0.05], req_time=10, enable_dedup=True))
+  check(probe)
+  # 2. update with OTHER ids of the same length
+  ids2 = rng.integers(1000, 6000, n).astype(np.int64)
+  both(lambda t: t.lookup(ids))
+  both(lambda t: t.apply_gradients(ids2, g, [0.05], req_time=11))
+  check(np.arange(0, 6100, dtype=np.int64))
+  # 3. the id tensor overwritten in place between lookup and update (same device buffer)
+  dev_ids = torch.tensor(ids, device="cuda:0")
+  h.t.lookup(dev_ids)
+  o.lookup(ids)
+  dev_ids.copy_(torch.tensor(ids2))
+  h.t = h.t.apply_gradients(dev_ids, torch.tensor(g, device="cuda:0"), 0, req_time=12)
+  h.lrs = [0.05]
+  o.apply_gradients(ids2, g, [0.05], req_time=12)
+  # (HipTable.apply_gradients sets lrs before the call; here the previous value 0.05 is in place)
+  check(np.arange(0, 6100, dtype=np.int64))
+  # 4. eviction between lookup and update: the cached slots may now belong to nobody
+  both(lambda t: t.lookup(ids))
+  both(lambda t: t.evict(12 + 5 * day))
+  assert o.size() == h.size() == 0
+  both(lambda t: t.apply_gradients(ids, g, [0.05], req_time=13 + 5 * day))
+  check(probe)
+  # 5. clear between lookup and update
+  both(lambda t: t.lookup(ids))
+  both(lambda t: t.clear())
+  both(lambda t: t.apply_gradients(ids[:100], g[:100], [0.05], req_time=14 + 5 * day))
+  check(probe)
+  # 6. growth (rehash) between lookup and update
+  both(lambda t: t.lookup(ids))
+  big = np.arange(10_000, 210_000, dtype=np.int64)
+  both(lambda t: t.assign_add(big, np.ones((len(big), 8), np.float32), req_time=15 + 5 * day))
+  both(lambda t: t.apply_gradients(ids, g, [0.05], req_time=16 + 5 * day, enable_dedup=True))
+  check(probe)
+  oi, orows, ots = o.export()
+  hi, hrows, hts = h.export()
+  assert np.array_equal(oi, hi) and np.array_equal(ots, hts)
+  assert np.array_equal(orows.view(np.uint32), hrows.view(np.uint32))
