@@ -738,9 +738,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       }
     }
   }
-#ifndef EXP_NO_TS
   if (sub == 0 && t.ts) t.ts[slot] = a.ts;
-#endif
 }
 
 // Segment classification (no-filter path): kClsItems sorted positions per thread. Segment heads
