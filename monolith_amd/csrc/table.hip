@@ -309,32 +309,11 @@ __global__ void __launch_bounds__(256) k_contains(TableDev t, const int64_t* __r
   }
 }
 
-// Write path, step 0: positions the preceding lookup already resolved (same id at the same
-// position) take their slot from the cache, one thread per id, fully coalesced; the rest is
-// marked kPendingSlot for k_find_or_claim.
-constexpr uint32_t kPendingSlot = 0xFFFFFFFEu;
-__global__ void __launch_bounds__(256) k_slots_from_cache(const int64_t* __restrict__ ids, int64_t n,
-                                                          const int64_t* __restrict__ cache_ids,
-                                                          const uint32_t* __restrict__ cache_slots,
-                                                          int64_t cache_n,
-                                                          uint32_t* __restrict__ slot_out) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    uint32_t s = kPendingSlot;
-    if (i < cache_n && cache_ids[i] == ids[i]) {
-      const uint32_t c = cache_slots[i];
-      if (c != kNoSlot) s = c;
-    }
-    slot_out[i] = s;
-  }
-}
-
 // Write path, step 1 (no filter): resolve every occurrence to its slot, inserting + initialising
 // missing keys (cuckoo_embedding_hash_table.cc:284-291). Emits (slot, occurrence index) pairs.
 __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t* __restrict__ ids,
                                                        int64_t n, uint32_t* __restrict__ slot_out,
-                                                       uint32_t* __restrict__ zero4,
-                                                       int pending_only) {
+                                                       uint32_t* __restrict__ zero4) {
   // the apply phase's four queue counters are cleared here: a separate memset costs ~10 us of
   // stream bubble between the sort and k_classify
   if (zero4 && blockIdx.x == 0 && threadIdx.x < 8) zero4[threadIdx.x] = 0;
@@ -346,31 +325,16 @@ __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t
     // is decided from them, anything else takes the claiming probe
     int64_t key[kIlp], k0[kIlp];
     uint64_t b[kIlp];
-    uint32_t cached[kIlp];  // slot k_slots_from_cache already resolved (pending_only)
-#pragma unroll
-    for (int q = 0; q < kIlp; ++q) cached[q] = kNoSlot;
-    if (pending_only) {
-      bool any = false;
-#pragma unroll
-      for (int q = 0; q < kIlp; ++q) {
-        if (i0 + q < n) {
-          const uint32_t sv = slot_out[i0 + q];
-          if (sv == kPendingSlot) any = true; else cached[q] = sv;
-        }
-      }
-      if (!any) continue;
-    }
 #pragma unroll
     for (int q = 0; q < kIlp; ++q) key[q] = i0 + q < n ? ids[i0 + q] : kEmpty;
 #pragma unroll
     for (int q = 0; q < kIlp; ++q) {
       b[q] = mix64((uint64_t)key[q]) & t.bucket_mask;
-      k0[q] = cached[q] == kNoSlot ? t.keys[b[q] * kBucket + sub] : kEmpty;
+      k0[q] = t.keys[b[q] * kBucket + sub];
     }
 #pragma unroll
     for (int q = 0; q < kIlp; ++q) {
       if (i0 + q >= n) continue;
-      if (cached[q] != kNoSlot) continue;  // its slot is in slot_out already
       const bool special = key[q] == kEmpty || key[q] == kTomb;
       uint32_t m = group_bits(!special && k0[q] == key[q], gshift);
       uint32_t slot;
@@ -388,6 +352,59 @@ __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t
         }
       }
       if (sub == 0) slot_out[i0 + q] = slot;
+    }
+  }
+}
+
+// Write path, step 1 when a lookup of the same positions came before: a wave checks 64
+// positions with coalesced loads (id now, id and slot then); a position whose id is unchanged and
+// was found takes its slot from the record, the others are probed, eight at a time, one per
+// sub-group. In the steady state this kernel is a 34 MB streaming read.
+__global__ void __launch_bounds__(256) k_claim_pending(TableDev t, const int64_t* __restrict__ ids,
+                                                       int64_t n, uint32_t* slot_out,
+                                                       uint32_t* __restrict__ zero4,
+                                                       const int64_t* __restrict__ cache_ids,
+                                                       const uint32_t* __restrict__ cache_slots,
+                                                       int64_t cache_n) {
+  if (zero4 && blockIdx.x == 0 && threadIdx.x < 8) zero4[threadIdx.x] = 0;
+  const int lane = threadIdx.x & 63, sub = lane_sub(), gshift = lane_gshift(), grp = lane >> 3;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / 64);
+  for (int64_t base = ((int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 64; base < n;
+       base += nwaves * 64) {
+    bool pend = false;
+    if (base + lane < n) {
+      const int64_t i = base + lane;
+      uint32_t sv = kNoSlot;
+      if (i < cache_n && cache_ids[i] == ids[i]) sv = cache_slots[i];
+      if (sv != kNoSlot) slot_out[i] = sv;
+      else pend = true;
+    }
+    unsigned long long m = __ballot(pend);
+    while (m) {  // wave-uniform: up to eight pending positions per round
+      // sub-group g takes the g-th set bit
+      unsigned long long rest = m;
+      int mine = -1;
+      for (int g = 0; g < 8; ++g) {
+        if (!rest) break;
+        const int b = __ffsll((long long)rest) - 1;
+        if (g == grp) mine = b;
+        rest &= rest - 1;
+      }
+      m = rest;
+      if (mine >= 0) {
+        const int64_t i = base + mine;
+        const int64_t key = ids[i];
+        bool claimed;
+        const uint32_t slot = group_find_or_claim(t, key, sub, gshift, &claimed);
+        if (claimed) {
+          group_init_row(t, key, slot, sub);
+          if (sub == 0) {
+            t.ts[slot] = 0;
+            atomicAdd(&t.counters[0], 1ull);
+          }
+        }
+        if (sub == 0) slot_out[i] = slot;
+      }
     }
   }
 }
@@ -1441,12 +1458,12 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
     uint32_t* slot_out = idx_in + n_al;
     uint32_t* idx_out = slot_out + n_al;
     void* tmp = idx_out + n_al;
-    const int cached = t->cache_n > 0 ? 1 : 0;
-    if (cached)
-      hipLaunchKernelGGL(k_slots_from_cache, dim3(grid_for(n, 1024)), dim3(256), 0, st, ids, n,
-                         t->cache_ids, t->cache_slots, t->cache_n, slot_in);
-    hipLaunchKernelGGL(k_find_or_claim, dim3(grid_for(n, 32 * kIlp)), dim3(256), 0, st, t->d, ids, n,
-                       slot_in, (uint32_t*)q_base, cached);
+    if (t->cache_n > 0)
+      hipLaunchKernelGGL(k_claim_pending, dim3(grid_for(n, 1024)), dim3(256), 0, st, t->d, ids, n,
+                         slot_in, (uint32_t*)q_base, t->cache_ids, t->cache_slots, t->cache_n);
+    else
+      hipLaunchKernelGGL(k_find_or_claim, dim3(grid_for(n, 32 * kIlp)), dim3(256), 0, st, t->d, ids, n,
+                         slot_in, (uint32_t*)q_base);
     MONO_HIP(hipGetLastError());
     if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
     // values = input positions (the sort's identity default): no index array to write and read
