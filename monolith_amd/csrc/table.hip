@@ -250,6 +250,10 @@ __device__ __forceinline__ void vstore(float* p, const float (&r)[V]) {
 // the kernel near 2.7 TB/s (Little's law). Each sub-group therefore works on kIlp ids at once:
 // kIlp bucket reads are issued back to back, then kIlp row reads.
 constexpr int kIlp = 4;
+#ifndef MONO_ILP_LOOKUP
+#define MONO_ILP_LOOKUP 4
+#endif
+constexpr int kIlpL = MONO_ILP_LOOKUP;  // ids in flight per sub-group in k_lookup
 template <int V>
 __global__ void __launch_bounds__(256) k_lookup(TableDev t, const int64_t* __restrict__ ids,
                                                 int64_t n, float* __restrict__ out,
@@ -258,33 +262,33 @@ __global__ void __launch_bounds__(256) k_lookup(TableDev t, const int64_t* __res
   const int sub = lane_sub(), gshift = lane_gshift();
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
   const int D = t.dim;
-  for (int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8) * kIlp; i0 < n;
-       i0 += ngroups * kIlp) {
-    int64_t key[kIlp], k0[kIlp];
-    uint64_t b[kIlp];
-    uint32_t slot[kIlp];
+  for (int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8) * kIlpL; i0 < n;
+       i0 += ngroups * kIlpL) {
+    int64_t key[kIlpL], k0[kIlpL];
+    uint64_t b[kIlpL];
+    uint32_t slot[kIlpL];
 #pragma unroll
-    for (int q = 0; q < kIlp; ++q) key[q] = i0 + q < n ? ids[i0 + q] : kEmpty;
+    for (int q = 0; q < kIlpL; ++q) key[q] = i0 + q < n ? ids[i0 + q] : kEmpty;
 #pragma unroll
-    for (int q = 0; q < kIlp; ++q) {
+    for (int q = 0; q < kIlpL; ++q) {
       b[q] = mix64((uint64_t)key[q]) & t.bucket_mask;
       k0[q] = t.keys[b[q] * kBucket + sub];
     }
 #pragma unroll
-    for (int q = 0; q < kIlp; ++q) slot[q] = group_find_pre(t, key[q], b[q], k0[q], sub, gshift);
-    if (cache_ids && sub < kIlp && i0 + sub < n) {  // lane q of the sub-group records id q
+    for (int q = 0; q < kIlpL; ++q) slot[q] = group_find_pre(t, key[q], b[q], k0[q], sub, gshift);
+    if (cache_ids && sub < kIlpL && i0 + sub < n) {  // lane q of the sub-group records id q
       int64_t ck = key[0];
       uint32_t cs = slot[0];
 #pragma unroll
-      for (int q = 1; q < kIlp; ++q)
+      for (int q = 1; q < kIlpL; ++q)
         if (sub == q) { ck = key[q]; cs = slot[q]; }
       cache_ids[i0 + sub] = ck;
       cache_slots[i0 + sub] = cs;
     }
     for (int e = sub * V; e < D; e += 8 * V) {
-      float r[kIlp][V];
+      float r[kIlpL][V];
 #pragma unroll
-      for (int q = 0; q < kIlp; ++q) {
+      for (int q = 0; q < kIlpL; ++q) {
         if (slot[q] != kNoSlot) {
           vload<V>(r[q], t.rows + (uint64_t)slot[q] * t.row_floats + e);
         } else {
@@ -293,7 +297,7 @@ __global__ void __launch_bounds__(256) k_lookup(TableDev t, const int64_t* __res
         }
       }
 #pragma unroll
-      for (int q = 0; q < kIlp; ++q)
+      for (int q = 0; q < kIlpL; ++q)
         if (i0 + q < n) vstore<V>(out + (i0 + q) * D + e, r[q]);
     }
   }
@@ -1269,7 +1273,7 @@ static int ensure_room(Table* t, int64_t incoming, hipStream_t st) {
 template <int V>
 static void launch_lookup(const Table* t, const int64_t* ids, int64_t n, float* out, hipStream_t st,
                           int64_t* cache_ids = nullptr, uint32_t* cache_slots = nullptr) {
-  hipLaunchKernelGGL(k_lookup<V>, dim3(grid_for(n, 32 * kIlp)), dim3(256), 0, st, t->d, ids, n, out,
+  hipLaunchKernelGGL(k_lookup<V>, dim3(grid_for(n, 32 * kIlpL)), dim3(256), 0, st, t->d, ids, n, out,
                      cache_ids, cache_slots);
 }
 
