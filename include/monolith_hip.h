@@ -30,7 +30,9 @@ extern "C" {
 enum {
   MONO_OPT_SGD = 0, MONO_OPT_ADAGRAD = 1, MONO_OPT_FTRL = 2,
   /* optimizer/{momentum,rmsprop,adadelta}_optimizer.cc */
-  MONO_OPT_MOMENTUM = 3, MONO_OPT_RMSPROP = 4, MONO_OPT_RMSPROP_V2 = 5, MONO_OPT_ADADELTA = 6
+  MONO_OPT_MOMENTUM = 3, MONO_OPT_RMSPROP = 4, MONO_OPT_RMSPROP_V2 = 5, MONO_OPT_ADADELTA = 6,
+  /* optimizer/{adam,amsgrad}_optimizer.cc: m | v (| vhat) per weight + beta1^t, beta2^t per row */
+  MONO_OPT_ADAM = 7, MONO_OPT_AMSGRAD = 8
 };
 enum { MONO_INIT_ZEROS = 0, MONO_INIT_ONES = 1, MONO_INIT_CONSTANT = 2, MONO_INIT_UNIFORM = 3 };
 
@@ -51,7 +53,10 @@ typedef struct {
   float averaging_ratio; /* Adadelta averaging_ratio (0.9) */
   float learning_rate;   /* RMSProp reads the CONFIG learning rate (rmsprop_optimizer.cc:59), not
                             the per-call tensor; default 0.01 */
-  int32_t use_nesterov;  /* Momentum */
+  int32_t use_nesterov;  /* Momentum, Adam, AMSGrad */
+  /* ABI version 3: */
+  float beta1;           /* Adam / AMSGrad (0.9) */
+  float beta2;           /* Adam / AMSGrad (0.99) */
 } mono_segment_cfg;
 
 typedef struct {

@@ -22,7 +22,7 @@ class SegCfg(C.Structure):  # mono_segment_cfg
               ("beta", C.c_float), ("init_kind", C.c_int32), ("init_a", C.c_float),
               ("init_b", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float),
               ("averaging_ratio", C.c_float), ("learning_rate", C.c_float),
-              ("use_nesterov", C.c_int32)]
+              ("use_nesterov", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float)]
 
 
 class TableCfg(C.Structure):  # mono_table_cfg

@@ -25,8 +25,9 @@ from monolith_amd import _lib, entry
 SGD, ADAGRAD, FTRL = entry.OPT_SGD, entry.OPT_ADAGRAD, entry.OPT_FTRL
 MOMENTUM, RMSPROP, RMSPROP_V2, ADADELTA = (entry.OPT_MOMENTUM, entry.OPT_RMSPROP,
                                            entry.OPT_RMSPROP_V2, entry.OPT_ADADELTA)
-# SingleOptimizerDump oneof field (optimizer.proto:216-231) and, per optimizer, the dump's repeated
-# float fields in ROW order: [(field number, which state slot of the row)]
+ADAM, AMSGRAD = entry.OPT_ADAM, entry.OPT_AMSGRAD
+# SingleOptimizerDump oneof field (optimizer.proto:216-231) and, per optimizer, the dump's float
+# fields in SERIALIZATION order: (field number, state slot of the row | "scalar k").
 _DUMP_FIELDS = {
     SGD: (2, []),
     ADAGRAD: (1, [(1, 0)]),            # norm
@@ -35,7 +36,24 @@ _DUMP_FIELDS = {
     MOMENTUM: (9, [(1, 0)]),           # n
     RMSPROP: (11, [(1, 0)]),           # n
     RMSPROP_V2: (12, [(1, 0)]),        # n
+    # m, v (, vhat) per weight, then the row's beta1^t, beta2^t (optional float fields)
+    ADAM: (7, [(1, 0), (2, 1), (3, "s0"), (4, "s1")]),
+    AMSGRAD: (8, [(1, 0), (2, 1), (3, 2), (4, "s0"), (5, "s1")]),
 }
+
+
+def _dump_parts(kind: int, d: int):
+  """(oneof field, [(field number, first row offset inside the segment's state, count)],
+  state floats of the segment)."""
+  field, parts = _DUMP_FIELDS[kind]
+  nslots = sum(1 for _, w in parts if not isinstance(w, str))
+  out = []
+  for fno, where in parts:
+    if isinstance(where, str):
+      out.append((fno, nslots * d + int(where[1:]), 1))
+    else:
+      out.append((fno, where * d, d))
+  return field, out, sum(c for _, _, c in out)
 
 
 def sharded_name(basename: str, idx: int, total: int) -> str:
@@ -106,7 +124,7 @@ def _read_varint(b, pos):
 
 
 def _opt_payload_len(kind: int, dim: int) -> int:
-  return 5 * dim * len(_DUMP_FIELDS[kind][1])
+  return 5 * _dump_parts(kind, dim)[2]
 
 
 def _len_prefixed(tag: int, n: int) -> bytes:
@@ -143,13 +161,13 @@ class DumpLayout:
     for d, k in self.segments:
       body = bytearray()
       marks = []
-      field, parts = _DUMP_FIELDS[k]
-      for fno, slot in parts:  # ascending field numbers = serialization order
-        for i in range(d):
+      field, parts, nfloats = _dump_parts(k, d)
+      for fno, off, cnt in parts:  # ascending field numbers = serialization order
+        for i in range(cnt):
           body.append((fno << 3) | 5)
-          marks.append((len(body), st + slot * d + i))
+          marks.append((len(body), st + off + i))
           body += b"\x00" * 4
-      st += len(parts) * d
+      st += nfloats
       tag = (field << 3) | 2
       single = _len_prefixed(tag, len(body)) + bytes(body)
       hdr = len(_len_prefixed(tag, len(body)))
@@ -322,17 +340,17 @@ class DumpLayout:
       n, p2 = _read_varint(single, p2) if single else (0, 0)
       body = single[p2:p2 + n]
       kind_field = tag >> 3
-      field, parts = _DUMP_FIELDS[k]
+      field, parts, nfloats = _dump_parts(k, d)
       if kind_field != field:
         raise ValueError("segment expects optimizer dump field %d, found field %d" %
                          (field, kind_field))
-      r = floats(body, [fno for fno, _ in parts])
-      for fno, slot in parts:
-        if len(r[fno]) != d:
+      r = floats(body, [fno for fno, _, _ in parts])
+      for fno, off, cnt in parts:
+        if len(r[fno]) != cnt:
           raise ValueError("optimizer dump field %d has %d values, expected %d" %
-                           (fno, len(r[fno]), d))
-        row[st + slot * d:st + (slot + 1) * d] = r[fno]
-      st += len(parts) * d
+                           (fno, len(r[fno]), cnt))
+        row[st + off:st + off + cnt] = r[fno]
+      st += nfloats
     return rid, row, np.uint32(ts & 0xFFFFFFFF)
 
 

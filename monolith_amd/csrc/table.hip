@@ -46,11 +46,25 @@ struct SegDev {
   float init_acc, wd, l1, l2, beta, init_a, init_b;
   float momentum, epsilon, rho, conf_lr;
   int nesterov;
+  float beta1, beta2;
 };
 
-// per-element optimizer state slots of a row: norm | (FTRL) zero; n; accum | accum_update
+// per-element optimizer state slots of a row: norm | (FTRL) zero; n; accum | accum_update;
+// m | v (| vhat)
 __host__ __device__ inline int opt_nstate(int kind) {
-  return kind == MONO_OPT_SGD ? 0 : (kind == MONO_OPT_FTRL || kind == MONO_OPT_ADADELTA) ? 2 : 1;
+  switch (kind) {
+    case MONO_OPT_SGD: return 0;
+    case MONO_OPT_FTRL: case MONO_OPT_ADADELTA: case MONO_OPT_ADAM: return 2;
+    case MONO_OPT_AMSGRAD: return 3;
+    default: return 1;
+  }
+}
+// per-row scalars behind a segment's state slots: Adam / AMSGrad keep beta1^t, beta2^t
+__host__ __device__ inline int opt_nscalar(int kind) {
+  return (kind == MONO_OPT_ADAM || kind == MONO_OPT_AMSGRAD) ? 2 : 0;
+}
+__host__ __device__ inline int opt_state_floats(int kind, int dim) {
+  return opt_nstate(kind) * dim + opt_nscalar(kind);
 }
 
 struct TableDev {  // passed to kernels by value
@@ -195,10 +209,14 @@ __device__ inline float row_init_value(const TableDev& t, int64_t key, int e) {
   }
   for (int s = 0; s < t.n_seg; ++s) {
     const SegDev& c = t.seg[s];
-    const int len = opt_nstate(c.opt_kind) * c.dim;
-    // Adagrad / FTRL: norm starts at initial_accumulator_value; every other state starts at 0
-    if (e >= c.st_off && e < c.st_off + len)
+    const int len = opt_state_floats(c.opt_kind, c.dim);
+    // Adagrad / FTRL: norm starts at initial_accumulator_value; Adam / AMSGrad: the row scalars
+    // start at beta1, beta2 (adam_optimizer.cc:40-51); every other state starts at 0
+    if (e >= c.st_off && e < c.st_off + len) {
+      const int k = e - c.st_off - opt_nstate(c.opt_kind) * c.dim;
+      if (k >= 0) return k == 0 ? c.beta1 : c.beta2;
       return (e - c.st_off < c.dim && c.opt_kind <= MONO_OPT_FTRL) ? c.init_acc : 0.f;
+    }
   }
   return 0.f;
 }
@@ -484,8 +502,13 @@ __device__ inline int64_t segment_end(const K* keys, int64_t j, int64_t n, K key
 
 // One optimizer step on one element. Non-contracted arithmetic
 // (-ffp-contract=off) with correctly rounded sqrt/div, i.e. the reference's baseline form.
+// third state slot + per-row scalars (generic path only; the specialised kernels pass a dummy)
+struct OptX {
+  float s2 = 0.f, b1p = 0.f, b2p = 0.f;
+};
+
 __device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, float g, float& w,
-                                         float& s0, float& s1) {
+                                         float& s0, float& s1, OptX& x) {
   if (kind == MONO_OPT_SGD) {  // sgd_optimizer.cc:36-44
     w -= lr * g;
   } else if (kind == MONO_OPT_ADAGRAD) {  // avx_utils.h:29-38
@@ -519,6 +542,25 @@ __device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, fl
     const double eta = rate / (double)(sqrtf(new_n) + 1);
     w = (float)((double)w - eta * dx);
     s0 = new_n;
+  } else if (kind == MONO_OPT_ADAM || kind == MONO_OPT_AMSGRAD) {
+    // adam_optimizer.cc:53-80 / amsgrad_optimizer.cc:55-86; s0 = m, s1 = v, x.s2 = vhat. The
+    // unqualified sqrt() of the reference resolves to ::sqrt(double), so the rate and the
+    // quotient are carried in double and rounded once.
+    const float rate = (float)((double)lr * sqrt((double)(1 - x.b2p)) / (double)(1 - x.b1p));
+    const float cur = g + c.wd * w;
+    const float new_m = s0 + (cur - s0) * (1 - c.beta1);
+    const float new_v = s1 + (cur * cur - s1) * (1 - c.beta2);
+    float den_v = new_v;
+    if (kind == MONO_OPT_AMSGRAD) {
+      x.s2 = fmaxf(x.s2, new_v);
+      den_v = x.s2;
+    }
+    const float num = c.nesterov ? (cur * (1 - c.beta1) + c.beta1 * new_m) * rate : new_m * rate;
+    w = (float)((double)w - (double)num / (sqrt((double)den_v) + (double)c.epsilon));
+    s0 = new_m;
+    s1 = new_v;
+    x.b1p *= c.beta1;  // every lane keeps its own copy: one multiplication per Optimize call
+    x.b2p *= c.beta2;
   } else {  // adadelta_optimizer.cc:50-66; s0 = accum, s1 = accum_update
     const float cur = g + c.wd * w;
     const float new_accum = s0 * c.rho + cur * cur * (1 - c.rho);
@@ -526,6 +568,32 @@ __device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, fl
     w = w - update * lr;
     s1 = s1 * c.rho + update * update * (1 - c.rho);
     s0 = new_accum;
+  }
+}
+
+// generic path: third state + row scalars of the segment that owns element e
+__device__ __forceinline__ void optx_load(const TableDev& t, const SegDev& sg, const float* row,
+                                          int e, bool fresh, int64_t key, OptX& x) {
+  const int ns = opt_nstate(sg.opt_kind);
+  if (ns >= 3) {
+    const int off = sg.st_off + 2 * sg.dim + (e - sg.w_off);
+    x.s2 = fresh ? row_init_value(t, key, off) : row[off];
+  }
+  if (opt_nscalar(sg.opt_kind)) {
+    const int off = sg.st_off + ns * sg.dim;
+    x.b1p = fresh ? row_init_value(t, key, off) : row[off];
+    x.b2p = fresh ? row_init_value(t, key, off + 1) : row[off + 1];
+  }
+}
+__device__ __forceinline__ void optx_store(const SegDev& sg, float* row, int e, const OptX& x) {
+  const int ns = opt_nstate(sg.opt_kind);
+  if (ns >= 3) row[sg.st_off + 2 * sg.dim + (e - sg.w_off)] = x.s2;
+  // The row scalars are written by the lane of the segment's LAST weight: rows wider than one
+  // pass (8 lanes x V, or 64 columns) are walked in ascending element order, and every pass
+  // loads before it stores, so no lane can still need the old value.
+  if (opt_nscalar(sg.opt_kind) && e == sg.w_off + sg.dim - 1) {
+    row[sg.st_off + ns * sg.dim] = x.b1p;
+    row[sg.st_off + ns * sg.dim + 1] = x.b2p;
   }
 }
 
@@ -661,6 +729,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
     const int e0 = c0 + sub * V;
     if (e0 >= D) continue;
     float w[V], s0[V], s1[V];
+    OptX ox[V];
     int kind[V];
     int segi[V];
     int st0_off[V], st1_off[V];
@@ -688,7 +757,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       for (int q = 0; q < V; ++q) {
         w[q] = row_init_value(t, key, e0 + q);
         s0[q] = opt_nstate(kind[q]) >= 1 ? row_init_value(t, key, st0_off[q]) : 0.f;
-        s1[q] = opt_nstate(kind[q]) == 2 ? row_init_value(t, key, st1_off[q]) : 0.f;
+        s1[q] = opt_nstate(kind[q]) >= 2 ? row_init_value(t, key, st1_off[q]) : 0.f;
       }
     } else {
       vload<V>(w, row + e0);
@@ -699,10 +768,14 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
 #pragma unroll
           for (int q = 0; q < V; ++q) {
             s0[q] = opt_nstate(kind[q]) >= 1 ? row[st0_off[q]] : 0.f;
-            s1[q] = opt_nstate(kind[q]) == 2 ? row[st1_off[q]] : 0.f;
+            s1[q] = opt_nstate(kind[q]) >= 2 ? row[st1_off[q]] : 0.f;
           }
         }
       }
+    }
+    if (OPTK == OPTK_MULTI && (need_state || fresh)) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) optx_load(t, t.seg[segi[q]], row, e0 + q, fresh, key, ox[q]);
     }
     // --- walk the occurrences in input order
     if (a.mode == MODE_ASSIGN) {
@@ -720,7 +793,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
         vload<V>(g, a.src + (uint64_t)a.sidx[p] * D + e0);
 #pragma unroll
         for (int q = 0; q < V; ++q)
-          opt_step(kind[q], t.seg[segi[q]], a.lr[segi[q]], g[q], w[q], s0[q], s1[q]);
+          opt_step(kind[q], t.seg[segi[q]], a.lr[segi[q]], g[q], w[q], s0[q], s1[q], ox[q]);
       }
     } else {  // MODE_OPT_DEDUP: in-order sum (bridge :251-266), then one step
       float acc[V];
@@ -743,7 +816,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       }
 #pragma unroll
       for (int q = 0; q < V; ++q)
-        opt_step(kind[q], t.seg[segi[q]], a.lr[segi[q]], acc[q], w[q], s0[q], s1[q]);
+        opt_step(kind[q], t.seg[segi[q]], a.lr[segi[q]], acc[q], w[q], s0[q], s1[q], ox[q]);
     }
     // --- store
     vstore<V>(row + e0, w);
@@ -754,7 +827,8 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
 #pragma unroll
         for (int q = 0; q < V; ++q) {
           if (opt_nstate(kind[q]) >= 1) row[st0_off[q]] = s0[q];
-          if (opt_nstate(kind[q]) == 2) row[st1_off[q]] = s1[q];
+          if (opt_nstate(kind[q]) >= 2) row[st1_off[q]] = s1[q];
+          optx_store(t.seg[segi[q]], row, e0 + q, ox[q]);
         }
       }
     }
@@ -877,6 +951,7 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         st1 = st0 + t.seg[segi].dim;
       }
       float w = 0.f, s0 = 0.f, s1 = 0.f, acc = 0.f;
+      OptX ox;
       bool have_acc = false;
       const bool need_state = MODE >= MODE_OPT_SEQ;
       const bool part = ls.part != kNoPart;  // one chunk of a split key: emit the chunk sum only
@@ -884,14 +959,16 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         if (ls.fresh) {
           w = row_init_value(t, ls.key, e);
           s0 = opt_nstate(kind) >= 1 ? row_init_value(t, ls.key, st0) : 0.f;
-          s1 = opt_nstate(kind) == 2 ? row_init_value(t, ls.key, st1) : 0.f;
+          s1 = opt_nstate(kind) >= 2 ? row_init_value(t, ls.key, st1) : 0.f;
         } else {
           w = row[e];
           if (need_state) {
             s0 = opt_nstate(kind) >= 1 ? row[st0] : 0.f;
-            s1 = opt_nstate(kind) == 2 ? row[st1] : 0.f;
+            s1 = opt_nstate(kind) >= 2 ? row[st1] : 0.f;
           }
         }
+        if (OPTK == OPTK_MULTI && (need_state || ls.fresh))
+          optx_load(t, t.seg[segi], row, e, ls.fresh != 0, ls.key, ox);
       }
       const SegDev& sg = t.seg[segi];
       const float lr = a.lr[segi];
@@ -951,10 +1028,10 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              opt_step(kind, sg, lr, q[k].x, w, s0, s1);
-              opt_step(kind, sg, lr, q[k].y, w, s0, s1);
-              opt_step(kind, sg, lr, q[k].z, w, s0, s1);
-              opt_step(kind, sg, lr, q[k].w, w, s0, s1);
+              opt_step(kind, sg, lr, q[k].x, w, s0, s1, ox);
+              opt_step(kind, sg, lr, q[k].y, w, s0, s1, ox);
+              opt_step(kind, sg, lr, q[k].z, w, s0, s1, ox);
+              opt_step(kind, sg, lr, q[k].w, w, s0, s1, ox);
             }
           }
         };
@@ -984,7 +1061,7 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         for (; r < rows; ++r) {
           const float v = tp[r];
           if (MODE == MODE_ASSIGN_ADD) w += v;
-          else if (MODE == MODE_OPT_SEQ) opt_step(kind, sg, lr, v, w, s0, s1);
+          else if (MODE == MODE_OPT_SEQ) opt_step(kind, sg, lr, v, w, s0, s1, ox);
           else acc = acc + v;
         }
       };
@@ -1025,11 +1102,12 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
       if (owner && part) {
         a.partials[(uint64_t)ls.part * D + e] = MODE == MODE_ASSIGN_ADD ? w : acc;
       } else if (owner) {
-        if (MODE == MODE_OPT_DEDUP) opt_step(kind, sg, lr, acc, w, s0, s1);
+        if (MODE == MODE_OPT_DEDUP) opt_step(kind, sg, lr, acc, w, s0, s1, ox);
         row[e] = w;
         if (need_state || ls.fresh) {
           if (opt_nstate(kind) >= 1) row[st0] = s0;
-          if (opt_nstate(kind) == 2) row[st1] = s1;
+          if (opt_nstate(kind) >= 2) row[st1] = s1;
+          if (OPTK == OPTK_MULTI) optx_store(sg, row, e, ox);
         }
       }
     }
@@ -1057,15 +1135,18 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
       }
       const bool need_state = a.mode >= MODE_OPT_SEQ;
       float w, s0 = 0.f, s1 = 0.f;
+      OptX ox;
+      if (OPTK == OPTK_MULTI && (need_state || sp.fresh))
+        optx_load(t, t.seg[segi], row, e, sp.fresh != 0, sp.key, ox);
       if (sp.fresh) {
         w = row_init_value(t, sp.key, e);
         s0 = opt_nstate(kind) >= 1 ? row_init_value(t, sp.key, st0) : 0.f;
-        s1 = opt_nstate(kind) == 2 ? row_init_value(t, sp.key, st1) : 0.f;
+        s1 = opt_nstate(kind) >= 2 ? row_init_value(t, sp.key, st1) : 0.f;
       } else {
         w = row[e];
         if (need_state) {
           s0 = opt_nstate(kind) >= 1 ? row[st0] : 0.f;
-          s1 = opt_nstate(kind) == 2 ? row[st1] : 0.f;
+          s1 = opt_nstate(kind) >= 2 ? row[st1] : 0.f;
         }
       }
       const float* pp = a.partials + (uint64_t)sp.pbase * D + e;
@@ -1074,12 +1155,13 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
       } else {
         float acc = pp[0];
         for (uint32_t p = 1; p < sp.nparts; ++p) acc = acc + pp[(uint64_t)p * D];
-        opt_step(kind, t.seg[segi], a.lr[segi], acc, w, s0, s1);
+        opt_step(kind, t.seg[segi], a.lr[segi], acc, w, s0, s1, ox);
       }
       row[e] = w;
       if (need_state || sp.fresh) {
         if (opt_nstate(kind) >= 1) row[st0] = s0;
-        if (opt_nstate(kind) == 2) row[st1] = s1;
+        if (opt_nstate(kind) >= 2) row[st1] = s1;
+        if (OPTK == OPTK_MULTI) optx_store(t.seg[segi], row, e, ox);
       }
     }
     if (threadIdx.x == 0 && t.ts) t.ts[sp.slot] = a.ts;
@@ -1559,7 +1641,7 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
   int w = 0;
   for (int s = 0; s < cfg->n_segments; ++s) {
     const mono_segment_cfg& c = cfg->segments[s];
-    if (c.dim <= 0 || c.opt_kind < 0 || c.opt_kind > MONO_OPT_ADADELTA || c.init_kind < 0 ||
+    if (c.dim <= 0 || c.opt_kind < 0 || c.opt_kind > MONO_OPT_AMSGRAD || c.init_kind < 0 ||
         c.init_kind > MONO_INIT_UNIFORM) {
       delete t;
       return fail("mono_table_create: bad segment %d (dim %d opt %d init %d)", s, c.dim,
@@ -1580,8 +1662,9 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
     sd.l1 = c.l1; sd.l2 = c.l2; sd.beta = c.beta; sd.init_a = c.init_a; sd.init_b = c.init_b;
     sd.momentum = c.momentum; sd.epsilon = c.epsilon; sd.rho = c.averaging_ratio;
     sd.conf_lr = c.learning_rate; sd.nesterov = c.use_nesterov;
+    sd.beta1 = c.beta1; sd.beta2 = c.beta2;
     wo += c.dim;
-    st += opt_nstate(c.opt_kind) * c.dim;
+    st += opt_state_floats(c.opt_kind, c.dim);
   }
   d.row_floats = st;
   d.seed = cfg->seed;

@@ -9,6 +9,7 @@ from typing import Any, Callable, Dict, List, Optional, Union
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_RMSPROP, OPT_RMSPROP_V2, OPT_ADADELTA = 3, 4, 5, 6
+OPT_ADAM, OPT_AMSGRAD = 7, 8
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT, INIT_UNIFORM = 0, 1, 2, 3
 
 
@@ -79,6 +80,31 @@ class RmspropV2Optimizer(Optimizer):  # entry.py:272-283, optimizer.proto:180-18
   weight_decay_factor: float = 0.0
   momentum: float = 0.9
   kind = OPT_RMSPROP_V2
+
+
+@dataclasses.dataclass
+class AdamOptimizer(Optimizer):  # entry.py:135-172, optimizer.proto:104-114
+  learning_rate: Optional[Any] = None
+  beta1: float = 0.9
+  beta2: float = 0.99
+  use_beta1_warmup: bool = False
+  weight_decay_factor: float = 0.0
+  use_nesterov: bool = False
+  epsilon: float = 0.01
+  warmup_steps: int = 0
+  kind = OPT_ADAM
+
+
+@dataclasses.dataclass
+class AmsgradOptimizer(Optimizer):  # entry.py:175-222, optimizer.proto:123-132
+  learning_rate: Optional[Any] = None
+  beta1: float = 0.9
+  beta2: float = 0.99
+  weight_decay_factor: float = 0.0
+  use_nesterov: bool = False
+  epsilon: float = 0.01
+  warmup_steps: int = 0
+  kind = OPT_AMSGRAD
 
 
 class Initializer:

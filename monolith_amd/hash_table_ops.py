@@ -85,7 +85,8 @@ class _TableResource:
       o, i = s.opt_config, s.init_config
       if not isinstance(o, (entry.SgdOptimizer, entry.AdagradOptimizer, entry.FtrlOptimizer,
                             entry.MomentumOptimizer, entry.RmspropOptimizer,
-                            entry.RmspropV2Optimizer, entry.AdadeltaOptimizer)):
+                            entry.RmspropV2Optimizer, entry.AdadeltaOptimizer,
+                            entry.AdamOptimizer, entry.AmsgradOptimizer)):
         raise ValueError("optimizer %r is out of scope of the MI355X hot path" % (o,))
       init_acc = getattr(o, "initial_accumulator_value", None)
       seg = _lib.SegCfg(
@@ -100,6 +101,8 @@ class _TableResource:
       conf_lr = getattr(o, "learning_rate", None)  # _convert_to_proto keeps plain numbers only
       seg.learning_rate = float(conf_lr) if isinstance(conf_lr, (int, float)) else 0.01
       seg.use_nesterov = int(bool(getattr(o, "use_nesterov", False)))
+      seg.beta1 = getattr(o, "beta1", 0.9)
+      seg.beta2 = getattr(o, "beta2", 0.99)
       if isinstance(i, entry.ConstantsInitializer):
         seg.init_a = i.constant
       elif isinstance(i, entry.RandomUniformInitializer):

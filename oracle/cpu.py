@@ -14,6 +14,7 @@ _LIB = None
 
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_RMSPROP, OPT_RMSPROP_V2, OPT_ADADELTA = 3, 4, 5, 6
+OPT_ADAM, OPT_AMSGRAD = 7, 8
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT, INIT_UNIFORM = 0, 1, 2, 3
 
 
@@ -23,7 +24,7 @@ class SegCfg(C.Structure):
               ("beta", C.c_float), ("init_kind", C.c_int32), ("init_a", C.c_float),
               ("init_b", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float),
               ("averaging_ratio", C.c_float), ("learning_rate", C.c_float),
-              ("use_nesterov", C.c_int32)]
+              ("use_nesterov", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float)]
 
 
 class TableCfg(C.Structure):
@@ -77,13 +78,14 @@ def _ptr_array(arrs):
 
 def seg(dim, opt="sgd", init="zeros", init_acc=0.1, weight_decay=0.0, l1=0.0, l2=0.0, beta=0.0,
         init_a=0.0, init_b=0.0, momentum=0.9, epsilon=0.01, averaging_ratio=0.9,
-        learning_rate=0.01, use_nesterov=False):
+        learning_rate=0.01, use_nesterov=False, beta1=0.9, beta2=0.99):
   ok = {"sgd": OPT_SGD, "adagrad": OPT_ADAGRAD, "ftrl": OPT_FTRL, "momentum": OPT_MOMENTUM,
-        "rmsprop": OPT_RMSPROP, "rmspropv2": OPT_RMSPROP_V2, "adadelta": OPT_ADADELTA}[opt]
+        "rmsprop": OPT_RMSPROP, "rmspropv2": OPT_RMSPROP_V2, "adadelta": OPT_ADADELTA,
+        "adam": OPT_ADAM, "amsgrad": OPT_AMSGRAD}[opt]
   ik = {"zeros": INIT_ZEROS, "ones": INIT_ONES, "constant": INIT_CONSTANT,
         "uniform": INIT_UNIFORM}[init]
   return SegCfg(dim, ok, init_acc, weight_decay, l1, l2, beta, ik, init_a, init_b, momentum,
-                epsilon, averaging_ratio, learning_rate, int(bool(use_nesterov)))
+                epsilon, averaging_ratio, learning_rate, int(bool(use_nesterov)), beta1, beta2)
 
 
 def make_table_cfg(segments, initial_capacity=1, default_expire_days=36500, slot_expire=None,

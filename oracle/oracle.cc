@@ -30,7 +30,7 @@
 namespace {
 
 enum { OPT_SGD = 0, OPT_ADAGRAD = 1, OPT_FTRL = 2, OPT_MOMENTUM = 3, OPT_RMSPROP = 4,
-       OPT_RMSPROP_V2 = 5, OPT_ADADELTA = 6 };
+       OPT_RMSPROP_V2 = 5, OPT_ADADELTA = 6, OPT_ADAM = 7, OPT_AMSGRAD = 8 };
 enum { INIT_ZEROS = 0, INIT_ONES = 1, INIT_CONSTANT = 2, INIT_UNIFORM = 3 };
 
 struct SegCfg {  // == mono_segment_cfg
@@ -43,14 +43,17 @@ struct SegCfg {  // == mono_segment_cfg
   float init_a, init_b;
   float momentum, epsilon, averaging_ratio, learning_rate;
   int32_t use_nesterov;
+  float beta1, beta2;
 };
 
-// floats of optimizer context per weight: SizeBytes() of the reference optimizers
-inline int state_slots(int kind) {
+// floats of optimizer context: SizeBytes() / sizeof(float) of the reference optimizers
+inline int state_floats(int kind, int dim) {
   switch (kind) {
     case OPT_SGD: return 0;
-    case OPT_FTRL: case OPT_ADADELTA: return 2;
-    default: return 1;
+    case OPT_FTRL: case OPT_ADADELTA: return 2 * dim;
+    case OPT_ADAM: return 2 * dim + 2;     // adam_optimizer.cc:29-31: m | v | beta1^t | beta2^t
+    case OPT_AMSGRAD: return 3 * dim + 2;  // amsgrad_optimizer.cc: m | v | vhat | powers
+    default: return dim;
   }
 }
 
@@ -270,7 +273,12 @@ struct Table {
           st[c.dim + i] = 0.f;
         }
       } else {  // momentum / rmsprop / adadelta Init: every context float = 0
-        for (int i = 0; i < state_slots(c.opt_kind) * c.dim; ++i) st[i] = 0.f;
+        const int nf = state_floats(c.opt_kind, c.dim);
+        for (int i = 0; i < nf; ++i) st[i] = 0.f;
+        if (c.opt_kind == OPT_ADAM || c.opt_kind == OPT_AMSGRAD) {  // adam_optimizer.cc:40-51
+          st[nf - 2] = c.beta1;
+          st[nf - 1] = c.beta2;
+        }
       }
     }
   }
@@ -341,6 +349,39 @@ struct Table {
           n[i] = new_n;
           num[i] = new_w;
         }
+      } else if (c.opt_kind == OPT_ADAM || c.opt_kind == OPT_AMSGRAD) {
+        // adam_optimizer.cc:53-80, amsgrad_optimizer.cc:55-86. `sqrt` is written unqualified
+        // there and resolves to ::sqrt(double) (checked with this toolchain: <cmath> only), so
+        // the expressions around it are evaluated in double, as C++ promotes them.
+        const bool ams = c.opt_kind == OPT_AMSGRAD;
+        float* m = st;
+        float* v = m + c.dim;
+        float* vhat = v + c.dim;  // AMSGrad only
+        float& beta1_power = (ams ? vhat : v)[c.dim];
+        float& beta2_power = (ams ? vhat : v)[c.dim + 1];
+        float lr_t = lr * sqrt(1 - beta2_power) / (1 - beta1_power);
+        for (int i = 0; i < c.dim; ++i) {
+          float cur_grad = g[i] + c.weight_decay * num[i];
+          float new_m = m[i] + (cur_grad - m[i]) * (1 - c.beta1);
+          float new_v = v[i] + (cur_grad * cur_grad - v[i]) * (1 - c.beta2);
+          float den = new_v;
+          if (ams) {
+            float new_vhat = std::max(vhat[i], new_v);
+            vhat[i] = new_vhat;
+            den = new_vhat;
+          }
+          float new_w = num[i];
+          if (c.use_nesterov) {
+            new_w -= ((cur_grad * (1 - c.beta1) + c.beta1 * new_m) * lr_t) / (sqrt(den) + c.epsilon);
+          } else {
+            new_w -= (new_m * lr_t) / (sqrt(den) + c.epsilon);
+          }
+          num[i] = new_w;
+          m[i] = new_m;
+          v[i] = new_v;
+        }
+        beta1_power *= c.beta1;
+        beta2_power *= c.beta2;
       } else if (c.opt_kind == OPT_ADADELTA) {  // adadelta_optimizer.cc:50-66
         float* accum = st;
         float* accum_update = st + c.dim;
@@ -451,7 +492,7 @@ void* orc_table_create(const TableCfg* cfg) {
   for (int s = 0; s < cfg->n_segments; ++s) {
     t->seg_st_off.push_back(st);
     const SegCfg& c = cfg->segments[s];
-    st += state_slots(c.opt_kind) * c.dim;
+    st += state_floats(c.opt_kind, c.dim);
   }
   t->row_floats = st;
   t->default_expire_days = cfg->default_expire_days;

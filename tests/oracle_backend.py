@@ -10,7 +10,8 @@ def seg_from_dict(d):
                  momentum=d.get("momentum", 0.9), epsilon=d.get("epsilon", 0.01),
                  averaging_ratio=d.get("averaging_ratio", 0.9),
                  learning_rate=d.get("learning_rate", 0.01),
-                 use_nesterov=d.get("use_nesterov", False))
+                 use_nesterov=d.get("use_nesterov", False), beta1=d.get("beta1", 0.9),
+                 beta2=d.get("beta2", 0.99))
 
 
 def make_table(cfg):

@@ -39,12 +39,21 @@ def classes():
                                  ("norm", 2, F.TYPE_FLOAT, R, None)])
   _msg(fd, "AdadeltaOptimizerDump", [("accum", 1, F.TYPE_FLOAT, R, None),
                                      ("accum_update", 2, F.TYPE_FLOAT, R, None)])
+  _msg(fd, "AdamOptimizerDump", [("m", 1, F.TYPE_FLOAT, R, None), ("v", 2, F.TYPE_FLOAT, R, None),
+                                 ("beta1_power", 3, F.TYPE_FLOAT, O, None),
+                                 ("beta2_power", 4, F.TYPE_FLOAT, O, None)])
+  _msg(fd, "AmsgradOptimizerDump", [("m", 1, F.TYPE_FLOAT, R, None), ("v", 2, F.TYPE_FLOAT, R, None),
+                                    ("vhat", 3, F.TYPE_FLOAT, R, None),
+                                    ("beta1_power", 4, F.TYPE_FLOAT, O, None),
+                                    ("beta2_power", 5, F.TYPE_FLOAT, O, None)])
   for n in ("MomentumOptimizerDump", "RmspropOptimizerDump", "RmspropV2OptimizerDump"):
     _msg(fd, n, [("n", 1, F.TYPE_FLOAT, R, None)])
   _msg(fd, "SingleOptimizerDump", [("adagrad", 1, F.TYPE_MESSAGE, O, "AdagradOptimizerDump"),
                                    ("sgd", 2, F.TYPE_MESSAGE, O, "SgdOptimizerDump"),
                                    ("ftrl", 3, F.TYPE_MESSAGE, O, "FtrlOptimizerDump"),
                                    ("adadelta", 6, F.TYPE_MESSAGE, O, "AdadeltaOptimizerDump"),
+                                   ("adam", 7, F.TYPE_MESSAGE, O, "AdamOptimizerDump"),
+                                   ("amsgrad", 8, F.TYPE_MESSAGE, O, "AmsgradOptimizerDump"),
                                    ("momentum", 9, F.TYPE_MESSAGE, O, "MomentumOptimizerDump"),
                                    ("rmsprop", 11, F.TYPE_MESSAGE, O, "RmspropOptimizerDump"),
                                    ("rmspropv2", 12, F.TYPE_MESSAGE, O, "RmspropV2OptimizerDump")])
@@ -87,6 +96,16 @@ def _entry_msg(cls, layout, rid, row, ts):
       s.adadelta.accum.extend(float(x) for x in row[cur:cur + d])
       s.adadelta.accum_update.extend(float(x) for x in row[cur + d:cur + 2 * d])
       cur += 2 * d
+    elif kind in (ck.ADAM, ck.AMSGRAD):
+      sub = s.adam if kind == ck.ADAM else s.amsgrad
+      sub.m.extend(float(x) for x in row[cur:cur + d])
+      sub.v.extend(float(x) for x in row[cur + d:cur + 2 * d])
+      cur += 2 * d
+      if kind == ck.AMSGRAD:
+        sub.vhat.extend(float(x) for x in row[cur:cur + d])
+        cur += d
+      sub.beta1_power, sub.beta2_power = float(row[cur]), float(row[cur + 1])
+      cur += 2
     elif kind in (ck.MOMENTUM, ck.RMSPROP, ck.RMSPROP_V2):
       sub = {ck.MOMENTUM: s.momentum, ck.RMSPROP: s.rmsprop, ck.RMSPROP_V2: s.rmspropv2}[kind]
       sub.n.extend(float(x) for x in row[cur:cur + d])
@@ -99,7 +118,8 @@ def _entry_msg(cls, layout, rid, row, ts):
 
 def test_entry_dump_encoder_equals_protobuf(classes):
   layout = ck.DumpLayout([(3, ck.ADAGRAD), (2, ck.FTRL), (4, ck.SGD), (1, ck.ADAGRAD),
-                          (2, ck.ADADELTA), (3, ck.MOMENTUM), (1, ck.RMSPROP), (2, ck.RMSPROP_V2)])
+                          (2, ck.ADADELTA), (3, ck.MOMENTUM), (1, ck.RMSPROP), (2, ck.RMSPROP_V2),
+                          (2, ck.ADAM), (3, ck.AMSGRAD)])
   rng = np.random.Generator(np.random.PCG64(11))
   n = 64
   ids = rng.integers(-2**62, 2**62, n)

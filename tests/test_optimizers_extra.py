@@ -52,6 +52,20 @@ def test_adadelta_reference_vectors():
   assert np.allclose(r[1][:2], [-0.0064035, -0.0061047], atol=1e-6)
 
 
+def test_adam_amsgrad_reference_vectors():
+  """adam_optimizer_test.cc:32-70, amsgrad_optimizer_test.cc:32-70 (FloatNear 1e-6)."""
+  for opt in ("adam", "amsgrad"):
+    r = _steps(opt, 1, [[10.0], [10.0]])
+    assert abs(r[0][0] - -0.00990099) < 1e-6 and abs(r[0][1] - 1) < 1e-4      # w, m
+    assert abs(r[1][0] - -0.01983060) < 1e-6
+    r = _steps(opt, 2, [[10.0, 1.0], [10.0, 1.0]])
+    assert np.allclose(r[0][:2], [-0.00990099, -0.00909091], atol=1e-6)
+    assert np.allclose(r[0][2:4], [1, 0.1], atol=1e-4)
+    assert np.allclose(r[1][:2], [-0.01983060, -0.01842895], atol=1e-6)
+    # row = w[2] | m[2] | v[2] | (vhat[2]) | beta1^t | beta2^t: powers after two steps
+    assert np.allclose(r[1][-2:], [0.9 ** 3, 0.99 ** 3], rtol=1e-6)
+
+
 def test_dump_layout_of_new_optimizers_matches_protobuf_field_numbers():
   """optimizer.proto:216-231: adadelta = 6 {accum 1, accum_update 2}, momentum = 9 {n 1},
   rmsprop = 11 {n 1}, rmspropv2 = 12 {n 1}."""
@@ -89,6 +103,15 @@ CASES = {
     "adadelta": {"segments": [{"dim": 16, "opt": "adadelta", "epsilon": 1e-3,
                                "averaging_ratio": 0.95, "weight_decay": 0.01, "init": "uniform",
                                "init_a": -0.1, "init_b": 0.1}]},
+    "adam": {"segments": [{"dim": 16, "opt": "adam", "weight_decay": 0.01, "init": "uniform",
+                           "init_a": -0.1, "init_b": 0.1}], "seed": 8},
+    "adam_nesterov": {"segments": [{"dim": 5, "opt": "adam", "use_nesterov": True, "beta1": 0.8,
+                                    "beta2": 0.95, "epsilon": 1e-4, "init": "ones"}]},
+    "amsgrad": {"segments": [{"dim": 8, "opt": "amsgrad", "epsilon": 1e-3, "init": "uniform",
+                              "init_a": -0.1, "init_b": 0.1}]},
+    "mixed_adam": {"segments": [{"dim": 2, "opt": "adam"}, {"dim": 3, "opt": "adagrad"},
+                                {"dim": 2, "opt": "amsgrad", "use_nesterov": True},
+                                {"dim": 1, "opt": "ftrl", "beta": 1.0}, {"dim": 4, "opt": "adam"}]},
     "mixed": {"segments": [{"dim": 1, "opt": "ftrl", "init_acc": 0.1, "beta": 1.0},
                            {"dim": 3, "opt": "adadelta"}, {"dim": 4, "opt": "momentum"},
                            {"dim": 2, "opt": "rmsprop"}, {"dim": 6, "opt": "adagrad"},
@@ -143,3 +166,24 @@ def test_new_optimizer_tables_save_and_restore(tmp_path):
                           y.view(np.uint32) if y.dtype == np.float32 else y)
   layout = ck.DumpLayout.from_table_config(hip_backend.table_config(cfg))
   assert layout.row_floats == h.row_floats == 20 + 2 + 6 + 4 + 2 + 6 + 2
+
+
+def test_adam_dump_bytes():
+  """AdamOptimizerDump = 7 {m 1, v 2, beta1_power 3, beta2_power 4}, AmsgradOptimizerDump = 8
+  {m 1, v 2, vhat 3, beta1_power 4, beta2_power 5} (optimizer.proto:116-140, :222-223)."""
+  import struct
+  from monolith_amd import checkpoint as ck
+  layout = ck.DumpLayout([(2, ck.ADAM), (1, ck.AMSGRAD)])
+  assert layout.row_floats == 3 + (2 * 2 + 2) + (3 + 2)
+  rows = np.arange(14, dtype=np.float32).reshape(1, 14) + 0.25
+  (rec,) = layout.encode(np.array([-5], np.int64), rows, np.array([300], np.uint32))
+  f = lambda *xs: b"".join(bytes([t]) + struct.pack("<f", v) for t, v in xs)
+  adam = f((0x0d, 3.25), (0x0d, 4.25), (0x15, 5.25), (0x15, 6.25), (0x1d, 7.25), (0x25, 8.25))
+  ams = f((0x0d, 9.25), (0x15, 10.25), (0x1d, 11.25), (0x25, 12.25), (0x2d, 13.25))
+  single = lambda field, body: bytes([(field << 3) | 2, len(body)]) + body
+  opt = b"".join(bytes([0x0a, len(x)]) + x for x in (single(7, adam), single(8, ams)))
+  exp = b"\x09" + struct.pack("<q", -5) + f((0x15, 0.25), (0x15, 1.25), (0x15, 2.25)) + \
+      bytes([0x1a, len(opt)]) + opt + b"\x20\xac\x02"
+  assert rec[0].tobytes() == exp
+  rid, row, ts = layout._decode_one(exp)
+  assert rid == -5 and ts == 300 and np.array_equal(row, rows[0])
