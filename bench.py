@@ -329,30 +329,30 @@ def main():
   D = 16
   lookup_bytes = n * (8 + 8 + 4 * D + 4 * D)
   update_bytes = n * (8 + 4 * D) + uniq * n * (8 + 2 * (4 * D + 4 * D) + 4)
-  # per kernel: resolve = id + key slot read, slot + index write; apply = grad rows +
+  # per kernel: resolve (k_claim_pending) = id + handed-over (id, slot) read, slot write; apply = grad rows +
   # row/state read+write + ts (the part of §8d's update figure this kernel moves)
   kern = {
       "k_lookup": (lk_ms, lookup_bytes),
-      "k_find_or_claim": (find_ms, n * (8 + 8)),
+      "k_claim_pending": (find_ms, n * (8 + 8 + 4) + n * 4),
       "radix_sort(slot,idx)": (sort_ms, 0),
       "k_apply": (apply_ms, n * 4 * D + uniq * n * (2 * (4 * D + 4 * D) + 4)),
   }
-  dom = max(("k_lookup", "k_find_or_claim", "k_apply"), key=lambda k: kern[k][0])
+  dom = max(("k_lookup", "k_claim_pending", "k_apply"), key=lambda k: kern[k][0])
   achieved = kern[dom][1] / (kern[dom][0] * 1e-3) / 1e9
   step_gbs = (lookup_bytes + update_bytes) / (ms_per_step * 1e-3) / 1e9
   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE,
   # separate rocprofv3 --pmc runs of this same command; calibration note in the summary file)
   traffic, traffic_src = None, None
   try:
-    with open(os.path.join(ROOT, "profiles", "r01_e_pmc_summary.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r01_f_pmc_summary.json")) as f:
       pmc = json.load(f)["kernels"]
-    members = {"k_lookup": ["mono::k_lookup<4>"], "k_find_or_claim": ["mono::k_find_or_claim"],
+    members = {"k_lookup": ["mono::k_lookup<4>"], "k_claim_pending": ["mono::k_claim_pending"],
                "k_apply": ["mono::k_classify", "mono::k_apply<2, 1>", "mono::k_apply_long<1, 3>",
                            "mono::k_combine<1>"]}[dom]
     if args.batch == 65536 and args.rows == 1e8 and args.skew == 3.0:
       traffic = sum((pmc[m]["FETCH_SIZE_KB_last_launch"] + pmc[m]["WRITE_SIZE_KB_last_launch"]) *
                     1024.0 for m in members)
-      traffic_src = "profiles/r01_e_pmc_summary.json (" + " + ".join(members) + ")"
+      traffic_src = "profiles/r01_f_pmc_summary.json (" + " + ".join(members) + ")"
   except (OSError, KeyError, ValueError):
     pass
 
