@@ -110,6 +110,11 @@ int mono_filter_set_state(void* filter, int64_t head, int64_t head_increment, in
  * pass of this process (csrc/sort.hip) ever gave up waiting for its predecessors, 0 otherwise, -1 on a HIP
  * error. Synchronises the device. */
 int mono_debug_sort_error(void);
+/* Test / measurement hook, no counterpart in the reference: stable sort of n (key, value) pairs on
+ * the low end_bit key bits (vin NULL = identity values), reps times; average ms per sort in
+ * *avg_ms (HIP events on the stream). Allocates and frees its own scratch. */
+int mono_debug_sort_pairs(const uint32_t* kin, const uint32_t* vin, int64_t n, int end_bit,
+                          uint32_t* kout, uint32_t* vout, int reps, float* avg_ms, void* stream);
 
 /* ---- touched-key set: runtime/hopscotch/hopscotch_hash_set.{h,cc},
  *      ops/touched_key_set_{op,insert_op,steal_op}.cc, touched_key_set_ops.py ----

@@ -117,6 +117,37 @@ __device__ __forceinline__ void wave_excl_scan_256(const uint32_t* in, uint32_t*
   }
 }
 
+// Stable rank of a wave's 16 x 64 elements among equal digits of the wave's span. Per round the
+// lanes with equal digits find each other through LDS: every lane ORs its lane bit into the
+// (wave, digit) mask word and reads the word back (one wave's LDS operations execute in order, and
+// OR commutes, so the result does not depend on how the hardware serialises the lanes); the lowest
+// peer then adds the group to the running (wave, digit) count and clears the mask for the next
+// round. (Eight ballots per element with per-lane 64-bit mask arithmetic cost 6 us of a 13 us
+// pass.) mask: this wave's kSortMaxDigits words, zero on entry and on return.
+__device__ __forceinline__ void rank_wave_span(const uint32_t (&key)[kSortItems], int64_t base,
+                                               int64_t n, int shift, uint32_t dmask, int lane,
+                                               uint32_t* cnt_w, unsigned long long* mask_w,
+                                               uint32_t (&rank)[kSortItems]) {
+  const unsigned long long bitl = 1ull << lane, lt = bitl - 1ull;
+#pragma unroll
+  for (int r = 0; r < kSortItems; ++r) {
+    const bool valid = base + r * 64 + lane < n;
+    const uint32_t d = (key[r] >> shift) & dmask;
+    if (valid) atomicOr(&mask_w[d], bitl);
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      const unsigned long long peers = mask_w[d];
+      const uint32_t prev = cnt_w[d];  // all peers read both words before the leader updates them
+      rank[r] = prev + (uint32_t)__popcll(peers & lt);
+      if ((peers & lt) == 0) {
+        cnt_w[d] = prev + (uint32_t)__popcll(peers);
+        mask_w[d] = 0ull;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
     const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, int64_t n, int shift,
     int bits, const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ dtot,
@@ -127,16 +158,21 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
   __shared__ uint32_t ltot[kSortMaxDigits];   // elements of this tile per digit
   __shared__ uint32_t lexc[kSortMaxDigits];   // ... exclusive scan = start of the digit's run
   __shared__ uint32_t gpre[kSortMaxDigits];   // global start of the digit
-  __shared__ uint32_t sk[kSortTile], sv[kSortTile];
+  // staging of the tile in digit order; before that (ranking) its first 16 KB hold the match masks
+  __shared__ __align__(8) uint32_t stage[2 * kSortTile];
+  uint32_t* const sk = stage;
+  uint32_t* const sv = stage + kSortTile;
+  unsigned long long* const match = reinterpret_cast<unsigned long long*>(stage);
   const int nd = 1 << bits;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < kSortWaves * kSortMaxDigits; i += kSortThreads)
+  for (int i = threadIdx.x; i < kSortWaves * kSortMaxDigits; i += kSortThreads) {
     (&cnt[0][0])[i] = 0;
+    match[i] = 0ull;
+  }
   for (int i = threadIdx.x; i < kSortMaxDigits; i += kSortThreads) nh[i] = 0;
   __syncthreads();
   const int64_t tile0 = (int64_t)blockIdx.x * kSortTile;
   const int64_t base = tile0 + (int64_t)w * (64 * kSortItems);
-  const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
@@ -146,22 +182,8 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
     val[r] = valid ? (vin ? vin[i] : (uint32_t)i) : 0u;
   }
   // stable rank inside the wave's 1024-element span
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    const bool valid = base + r * 64 + lane < n;
-    const uint32_t d = (key[r] >> shift) & (uint32_t)(nd - 1);
-    unsigned long long peers = __ballot(valid);
-    for (int b = 0; b < bits; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
-    }
-    if (valid) {
-      const uint32_t prev = cnt[w][d];  // all peers read the word before the leader updates it
-      rank[r] = prev + (uint32_t)__popcll(peers & lt);
-      if ((peers & lt) == 0) cnt[w][d] = prev + (uint32_t)__popcll(peers);
-    }
-  }
+  rank_wave_span(key, base, n, shift, (uint32_t)(nd - 1), lane, cnt[w],
+                 match + (size_t)w * kSortMaxDigits, rank);
   if (next_bits > 0) {
 #pragma unroll
     for (int r = 0; r < kSortItems; ++r)
@@ -224,6 +246,29 @@ constexpr int kFusedMaxPasses = 4;
 constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr uint32_t kRowReady = 0x80000000u;  // a tile holds at most 8192 elements
 
+constexpr int kLbGroup = 16;                                // tiles per look-back group
+constexpr int kLbMaxGroups = kFusedMaxTiles / kLbGroup;     // 32
+
+// two published words (count | kRowReady each) per 8-byte relaxed load; a word validates itself
+__device__ __forceinline__ unsigned long long lb_load(const uint32_t* row, int l2) {
+  return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(row) + l2, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long lb_wait(unsigned long long v, const uint32_t* row,
+                                                      int l2, uint32_t* err) {
+  const unsigned long long both = ((unsigned long long)kRowReady << 32) | kRowReady;
+  uint32_t spins = 0;
+  while ((v & both) != both) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > kSpinLimit) {
+      atomicExch(err, 1u);
+      break;
+    }
+    v = lb_load(row, l2);
+  }
+  return v;
+}
+
 struct FusedPass {
   int shift[kFusedMaxPasses];
   int bits[kFusedMaxPasses];
@@ -232,7 +277,8 @@ struct FusedPass {
 
 __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
     const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, int64_t n, int shift,
-    int bits, int tiles, const uint32_t* __restrict__ dhist, uint32_t* rows, int next_shift,
+    int bits, int tiles, const uint32_t* __restrict__ dhist, uint32_t* rows, uint32_t* grows,
+    int next_shift,
     int next_bits, uint32_t* dhist_next, uint32_t* ticket, uint32_t* err,
     uint32_t* __restrict__ kout, uint32_t* __restrict__ vout) {
   __shared__ uint32_t nh[kSortMaxDigits];  // this tile's histogram of the NEXT pass's digit
@@ -240,20 +286,25 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
   __shared__ uint32_t ltot[kSortMaxDigits];
   __shared__ uint32_t lexc[kSortMaxDigits];
   __shared__ uint32_t gpre[kSortMaxDigits];
-  __shared__ uint32_t tpre[4][kSortMaxDigits];  // counts of the preceding tiles (four groups)
-  __shared__ uint32_t sk[kSortTile], sv[kSortTile];
+  __shared__ uint32_t tpre[4][kSortMaxDigits];  // counts of the preceding tiles (four thread sets)
+  // staging of the tile in digit order; before that (ranking) its first 16 KB hold the match masks
+  __shared__ __align__(8) uint32_t stage[2 * kSortTile];
+  uint32_t* const sk = stage;
+  uint32_t* const sv = stage + kSortTile;
+  unsigned long long* const match = reinterpret_cast<unsigned long long*>(stage);
   __shared__ uint32_t s_tile;
   const int nd = 1 << bits;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-  for (int i = threadIdx.x; i < kSortWaves * kSortMaxDigits; i += kSortThreads)
+  for (int i = threadIdx.x; i < kSortWaves * kSortMaxDigits; i += kSortThreads) {
     (&cnt[0][0])[i] = 0;
+    match[i] = 0ull;
+  }
   for (int i = threadIdx.x; i < kSortMaxDigits; i += kSortThreads) nh[i] = 0;
   __syncthreads();
   const int tile = (int)s_tile;
   const int64_t tile0 = (int64_t)tile * kSortTile;
   const int64_t base = tile0 + (int64_t)w * (64 * kSortItems);
-  const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
 #pragma unroll
   for (int r = 0; r < kSortItems; ++r) {
@@ -262,22 +313,8 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
     key[r] = valid ? kin[i] : 0u;
     val[r] = valid ? (vin ? vin[i] : (uint32_t)i) : 0u;
   }
-#pragma unroll
-  for (int r = 0; r < kSortItems; ++r) {
-    const bool valid = base + r * 64 + lane < n;
-    const uint32_t d = (key[r] >> shift) & (uint32_t)(nd - 1);
-    unsigned long long peers = __ballot(valid);
-    for (int b = 0; b < bits; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const unsigned long long bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
-    }
-    if (valid) {
-      const uint32_t prev = cnt[w][d];
-      rank[r] = prev + (uint32_t)__popcll(peers & lt);
-      if ((peers & lt) == 0) cnt[w][d] = prev + (uint32_t)__popcll(peers);
-    }
-  }
+  rank_wave_span(key, base, n, shift, (uint32_t)(nd - 1), lane, cnt[w],
+                 match + (size_t)w * kSortMaxDigits, rank);
   __syncthreads();
   for (int d = threadIdx.x; d < nd; d += kSortThreads) {
     uint32_t run = 0;
@@ -305,48 +342,62 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
       if (base + r * 64 + lane < n)
         atomicAdd(&nh[(key[r] >> next_shift) & (uint32_t)((1 << next_bits) - 1)], 1u);
   }
-  // counts of the tiles before this one (smaller tickets: all of them are running and publish
-  // before they wait for anything). Four groups of 128 threads split the tiles; a thread reads
-  // two digits per 8-byte load, eight loads in flight.
+  // counts of the tiles before this one, in two levels: tiles form groups of kLbGroup; the last
+  // tile of a group publishes the group's total (its own look-back inside the group + its count),
+  // so a tile reads at most kLbGroup - 1 tile rows and tiles / kLbGroup group rows instead of
+  // every tile before it. Smaller tickets are already running and publish before they wait, and
+  // a group total waits on tile rows only: every wait ends. Four sets of 128 threads split the
+  // rows; a thread reads two digits per 8-byte load, all its loads of a level in flight.
   {
-    const int grp = threadIdx.x >> 7, l2 = threadIdx.x & 127;
-    const int per = (tile + 3) >> 2;
-    const int t0 = min(tile, grp * per), t1 = min(tile, t0 + per);
+    const int set = threadIdx.x >> 7, l2 = threadIdx.x & 127;
+    const int g = tile / kLbGroup, g0 = g * kLbGroup;
+    const bool act = 2 * l2 < nd;
     uint32_t sum0 = 0, sum1 = 0;
-    if (2 * l2 < nd) {
-      const unsigned long long both = ((unsigned long long)kRowReady << 32) | kRowReady;
-      for (int tb = t0; tb < t1; tb += 8) {
-        unsigned long long v[8];
+    if (act) {
+      unsigned long long v[kLbGroup / 4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int t = min(tb + u, t1 - 1);
-          v[u] = __hip_atomic_load(
-              reinterpret_cast<const unsigned long long*>(&rows[(size_t)t * kSortMaxDigits]) + l2,
-              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+      for (int u = 0; u < kLbGroup / 4; ++u) {
+        const int t = g0 + set + 4 * u;
+        v[u] = t < tile ? lb_load(rows + (size_t)t * kSortMaxDigits, l2) : 0ull;
+      }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (tb + u >= t1) break;
-          uint32_t spins = 0;
-          while ((v[u] & both) != both) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > kSpinLimit) {
-              atomicExch(err, 1u);
-              break;
-            }
-            v[u] = __hip_atomic_load(
-                reinterpret_cast<const unsigned long long*>(&rows[(size_t)(tb + u) * kSortMaxDigits]) + l2,
-                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+      for (int u = 0; u < kLbGroup / 4; ++u) {
+        const int t = g0 + set + 4 * u;
+        if (t < tile) {
+          v[u] = lb_wait(v[u], rows + (size_t)t * kSortMaxDigits, l2, err);
           sum0 += (uint32_t)v[u] & ~kRowReady;
           sum1 += (uint32_t)(v[u] >> 32) & ~kRowReady;
         }
       }
     }
-    if (2 * l2 < kSortMaxDigits) {
-      tpre[grp][2 * l2] = sum0;
-      tpre[grp][2 * l2 + 1] = sum1;
+    tpre[set][2 * l2] = sum0;
+    tpre[set][2 * l2 + 1] = sum1;
+    __syncthreads();
+    if (tile % kLbGroup == kLbGroup - 1)
+      for (int d = threadIdx.x; d < nd; d += kSortThreads)
+        __hip_atomic_store(&grows[(size_t)g * kSortMaxDigits + d],
+                           (tpre[0][d] + tpre[1][d] + tpre[2][d] + tpre[3][d] + ltot[d]) | kRowReady,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (act) {
+      unsigned long long v[kLbMaxGroups / 4];
+#pragma unroll
+      for (int u = 0; u < kLbMaxGroups / 4; ++u) {
+        const int gg = set + 4 * u;
+        v[u] = gg < g ? lb_load(grows + (size_t)gg * kSortMaxDigits, l2) : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < kLbMaxGroups / 4; ++u) {
+        const int gg = set + 4 * u;
+        if (gg < g) {
+          v[u] = lb_wait(v[u], grows + (size_t)gg * kSortMaxDigits, l2, err);
+          sum0 += (uint32_t)v[u] & ~kRowReady;
+          sum1 += (uint32_t)(v[u] >> 32) & ~kRowReady;
+        }
+      }
     }
+    tpre[set][2 * l2] = sum0;
+    tpre[set][2 * l2 + 1] = sum1;
   }
   __syncthreads();
   if (next_bits > 0)
@@ -394,7 +445,7 @@ size_t sort_pairs_tmp_bytes(size_t n, int end_bit) {
   // fused passes: digit histograms, flags, tickets, error word, per-pass tile rows
   if (tiles <= (size_t)kFusedMaxTiles && passes <= kFusedMaxPasses)
     b += 256 + kFusedMaxPasses * (kSortMaxDigits + 16) * sizeof(uint32_t) +
-         (size_t)passes * tiles * kSortMaxDigits * sizeof(uint32_t);
+         (size_t)passes * (tiles + kLbMaxGroups) * kSortMaxDigits * sizeof(uint32_t);
   return b;
 }
 
@@ -426,7 +477,8 @@ int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uin
     uint32_t* dhist = (uint32_t*)q;                                   // [passes][256]
     uint32_t* ctl = dhist + kFusedMaxPasses * kSortMaxDigits;         // tickets [4], err
     uint32_t* rows = ctl + 16 * kFusedMaxPasses;                      // [passes][tiles][256]
-    const int64_t zero_words = (int64_t)(rows - dhist) + (int64_t)passes * tiles * kSortMaxDigits;
+    uint32_t* grows = rows + (size_t)passes * tiles * kSortMaxDigits;  // [passes][32][256]
+    const int64_t zero_words = (int64_t)(grows - dhist) + (int64_t)passes * kLbMaxGroups * kSortMaxDigits;
     FusedPass fp{};
     fp.passes = passes;
     int sh = 0;
@@ -460,6 +512,7 @@ int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uin
                          (int64_t)n, fp.shift[ps], fp.bits[ps], tiles,
                          dhist + ps * kSortMaxDigits,
                          rows + (size_t)ps * tiles * kSortMaxDigits,
+                         grows + (size_t)ps * kLbMaxGroups * kSortMaxDigits,
                          more ? fp.shift[ps + 1] : 0, more ? fp.bits[ps + 1] : 0,
                          dhist + (more ? ps + 1 : ps) * kSortMaxDigits, ctl + ps,
                          g_sort_err, dst_k, dst_v);
@@ -504,4 +557,32 @@ extern "C" int mono_debug_sort_error(void) {
       hipMemcpy(&v, mono::g_sort_err, 4, hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
   return (int)v;
+}
+
+// Test / measurement hook: sort n pairs on the low end_bit key bits (vin NULL = identity values),
+// reps times, average milliseconds per sort (HIP events on the stream) in *avg_ms.
+extern "C" int mono_debug_sort_pairs(const uint32_t* kin, const uint32_t* vin, int64_t n,
+                                     int end_bit, uint32_t* kout, uint32_t* vout, int reps,
+                                     float* avg_ms, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  MONO_REQUIRE(n >= 0 && reps >= 1, "mono_debug_sort_pairs: bad arguments");
+  const size_t bytes = mono::sort_pairs_tmp_bytes((size_t)n, end_bit);
+  void* tmp = nullptr;
+  MONO_HIP(hipMalloc(&tmp, bytes));
+  hipEvent_t e0, e1;
+  MONO_HIP(hipEventCreate(&e0));
+  MONO_HIP(hipEventCreate(&e1));
+  int rc = 0;
+  MONO_HIP(hipEventRecord(e0, st));
+  for (int r = 0; r < reps && rc == 0; ++r)
+    rc = mono::sort_pairs_u32(kin, kout, vin, vout, (size_t)n, end_bit, tmp, bytes, st);
+  MONO_HIP(hipEventRecord(e1, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  float ms = 0.f;
+  MONO_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (avg_ms) *avg_ms = ms / (float)reps;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  MONO_HIP(hipFree(tmp));
+  return rc;
 }

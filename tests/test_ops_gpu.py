@@ -293,3 +293,45 @@ def test_sort_paths_small_fused_and_large_three_kernel():
   fn = _lib.lib.mono_debug_sort_error
   fn.restype = C.c_int
   assert fn() == 0
+
+
+def _sort_pairs(keys, bits, reps=1):
+  import ctypes as C
+  import torch
+  from monolith_amd import _lib
+  fn = _lib.lib.mono_debug_sort_pairs
+  fn.restype = C.c_int
+  n = keys.numel()
+  ko = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")
+  vo = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")
+  ms = C.c_float(0)
+  _lib.check(fn(_lib.vp(keys), None, C.c_int64(n), C.c_int(bits), _lib.vp(ko), _lib.vp(vo),
+                C.c_int(reps), C.byref(ms), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+  return ko[:n].cpu().numpy().view(np.uint32), vo[:n].cpu().numpy().view(np.uint32), ms.value
+
+
+def test_sort_pairs_two_level_lookback():
+  """The fused passes sum the tiles before a tile in two levels (groups of 16 tiles): sizes on
+  both sides of every group boundary, skewed and constant keys, against numpy's stable argsort."""
+  import ctypes as C
+  import torch
+  from monolith_amd import _lib
+  rng = np.random.Generator(np.random.PCG64(5))
+  T8 = 8192
+  for n, bits in ((1, 9), (T8 + 1, 16), (15 * T8, 28), (16 * T8, 28), (16 * T8 + 1, 28),
+                  (17 * T8 - 5, 20), (33 * T8 + 7, 29), (208 * T8, 28), (511 * T8 + 9, 32),
+                  (512 * T8, 17)):
+    k = rng.integers(0, 1 << bits, n, dtype=np.uint64).astype(np.uint32)
+    if n > 100000:
+      k[rng.integers(0, n, n // 3)] = k[0]               # one hot key
+      k[n // 2: n // 2 + 30000] = np.uint32((1 << bits) - 1)
+    ko, vo, _ = _sort_pairs(torch.from_numpy(k.view(np.int32)).cuda(), bits)
+    order = np.argsort(k, kind="stable").astype(np.uint32)
+    assert np.array_equal(vo, order), (n, bits)
+    assert np.array_equal(ko, k[order]), (n, bits)
+  k = np.full(40 * T8, 7, dtype=np.uint32)
+  ko, vo, _ = _sort_pairs(torch.from_numpy(k.view(np.int32)).cuda(), 28)
+  assert np.array_equal(vo, np.arange(k.size, dtype=np.uint32))
+  fn = _lib.lib.mono_debug_sort_error
+  fn.restype = C.c_int
+  assert fn() == 0
