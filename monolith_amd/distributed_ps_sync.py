@@ -35,13 +35,17 @@ def _world(group=None) -> Tuple[int, int]:
   return 0, 1
 
 
+def _forced_collective() -> bool:
+  return (os.environ.get("MONOLITH_AMD_FORCE_COLLECTIVE") == "1" and dist.is_available() and
+          dist.is_initialized())
+
+
 def alltoall(tensor: torch.Tensor, splits, recv_splits=None, group=None):
   """hvd.alltoall(tensor, splits[, recv_splits]) on dim 0. Returns (received, recv_splits).
   `splits` / `recv_splits` are host int sequences (length world)."""
   rank, world = _world(group)
   splits = [int(x) for x in splits]
-  if world == 1 and not (os.environ.get("MONOLITH_AMD_FORCE_COLLECTIVE") == "1" and
-                         dist.is_available() and dist.is_initialized()):
+  if world == 1 and not _forced_collective():
     # (MONOLITH_AMD_FORCE_COLLECTIVE=1 sends even a one-rank exchange through the backend: the
     # way to exercise the RCCL calls on a single-GPU box)
     return tensor, splits
@@ -103,16 +107,24 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
 
     # M: num_of_ids, N: num_of_shards, K: num_of_merged_tables, E: total embedding floats.
     # id_flat_t: [M'], id_size_flat_t: [K*N] (source-shard major)
+    # The per-(shard, slot) counts travel first (fixed size, K per peer): their row sums are the
+    # FID counts every peer is about to send, so the FID exchange needs no size message of its
+    # own (one collective and one host synchronisation fewer per step than hvd.alltoall's).
     shard_sizes_h = [int(x) for x in torch.as_tensor(shard_sizes).tolist()]
-    id_flat_t, _ = alltoall(all_fids, shard_sizes_h, group=self._group)
     sss = torch.as_tensor(sharded_slot_sizes, dtype=torch.int32)
-    sss_dev = sss.to(all_fids.device)
-    id_size_flat_t, _ = alltoall(sss_dev, [slot_num] * self._shard_num,
-                                 recv_splits=[slot_num] * self._shard_num, group=self._group)
+    if _world(self._group)[1] == 1 and not _forced_collective():
+      id_size_flat_h = sss.cpu()
+    else:
+      id_size_flat_t, _ = alltoall(sss.to(all_fids.device), [slot_num] * self._shard_num,
+                                   recv_splits=[slot_num] * self._shard_num, group=self._group)
+      id_size_flat_h = id_size_flat_t.cpu()
+    recv_fid_splits = id_size_flat_h.reshape(self._shard_num, slot_num).sum(1).tolist()
+    id_flat_t, _ = alltoall(all_fids, shard_sizes_h, recv_splits=recv_fid_splits,
+                            group=self._group)
     auxiliary_bundle["shard_sizes"] = shard_sizes
     auxiliary_bundle["fused_embedding_offsets"] = fused_embedding_offsets
     auxiliary_bundle["id_flat_t"] = id_flat_t
-    auxiliary_bundle["id_size_flat_t"] = id_size_flat_t.cpu()
+    auxiliary_bundle["id_size_flat_t"] = id_size_flat_h
 
     # fused_embeddings: [E], embedding_splits: [N], id_offsets / emb_offsets: [K*N]
     fused_embeddings, embedding_splits, id_offsets, emb_offsets, _ = \

@@ -19,8 +19,8 @@ tr = np.zeros(512 * 16, dtype=np.uint64)
 assert lib.mono_debug_sort_trace(C.c_void_p(tr.ctypes.data)) == 0
 tr = tr.reshape(512, 16)[:208].astype(np.int64)
 t0 = tr[:, 0].min()
-names = ["start", "loaded", "ranked", "published", "lbA", "grp-pub", "lbB", "staged", "end"][:int(sys.argv[2]) if len(sys.argv) > 2 else 9]
-NS = len(names)
+NS = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+names = ["s%d" % i for i in range(NS)]
 rel = (tr[:, :NS] - t0) / 100.0   # us
 order = np.argsort(tr[:, 15])
 rel = rel[order]

@@ -1,7 +1,8 @@
 """Instrumented copy of sort.hip for scripts/exp_sort_trace.py: stamps wall_clock64 after the load
 and after every __syncthreads of k_sort_fused into a device array. Builds
 scripts/bin/libmonolith_hip_trace.so from a scratch tree under /tmp; the product is not touched."""
-import os, re, shutil, subprocess
+import os, re, shutil, subprocess, sys
+KERNEL = sys.argv[1] if len(sys.argv) > 1 else "k_sort_fused"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = "/tmp/sort_trace"
 shutil.rmtree(dst, ignore_errors=True)
@@ -14,8 +15,8 @@ for f in os.listdir(root + "/include"):
 p = dst + "/monolith_amd/csrc/sort.hip"
 s = open(p).read()
 s = s.replace("namespace mono {\n", "namespace mono {\n__device__ unsigned long long g_trace[512 * 16];\n", 1)
-a = s.index("__global__ void __launch_bounds__(kSortThreads) k_sort_fused(")
-b = s.index("static uint32_t* g_sort_err")
+a = s.index("__global__ void __launch_bounds__(kSortThreads) %s(" % KERNEL)
+b = s.index("\n}\n", a) + 3
 body = s[a:b]
 ld = "    val[r] = valid ? (vin ? vin[i] : (uint32_t)i) : 0u;\n  }\n"
 body = body.replace(ld, ld + "  if (threadIdx.x == 0 && (key[15] ^ val[15]) != 0xdeadbeefu) g_trace[blockIdx.x * 16 + 1] = wall_clock64();\n", 1)

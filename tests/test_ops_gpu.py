@@ -311,16 +311,17 @@ def _sort_pairs(keys, bits, reps=1):
 
 
 def test_sort_pairs_two_level_lookback():
-  """The fused passes sum the tiles before a tile in two levels (groups of 16 tiles): sizes on
-  both sides of every group boundary, skewed and constant keys, against numpy's stable argsort."""
+  """Up to 512 tiles the fused passes sum the tiles before a tile in two levels (groups of 16
+  tiles), beyond that three kernels per pass: sizes on both sides of every boundary, skewed and
+  constant keys, against numpy's stable argsort."""
   import ctypes as C
   import torch
   from monolith_amd import _lib
   rng = np.random.Generator(np.random.PCG64(5))
   T8 = 8192
   for n, bits in ((1, 9), (T8 + 1, 16), (15 * T8, 28), (16 * T8, 28), (16 * T8 + 1, 28),
-                  (17 * T8 - 5, 20), (33 * T8 + 7, 29), (208 * T8, 28), (511 * T8 + 9, 32),
-                  (512 * T8, 17)):
+                  (17 * T8 - 5, 20), (33 * T8 + 7, 29), (208 * T8, 28), (256 * T8, 7), (256 * T8 + 1, 23),
+                  (511 * T8 + 9, 32), (512 * T8, 17), (513 * T8 + 5, 26)):
     k = rng.integers(0, 1 << bits, n, dtype=np.uint64).astype(np.uint32)
     if n > 100000:
       k[rng.integers(0, n, n // 3)] = k[0]               # one hot key
