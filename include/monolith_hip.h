@@ -32,7 +32,9 @@ enum {
   /* optimizer/{momentum,rmsprop,adadelta}_optimizer.cc */
   MONO_OPT_MOMENTUM = 3, MONO_OPT_RMSPROP = 4, MONO_OPT_RMSPROP_V2 = 5, MONO_OPT_ADADELTA = 6,
   /* optimizer/{adam,amsgrad}_optimizer.cc: m | v (| vhat) per weight + beta1^t, beta2^t per row */
-  MONO_OPT_ADAM = 7, MONO_OPT_AMSGRAD = 8
+  MONO_OPT_ADAM = 7, MONO_OPT_AMSGRAD = 8,
+  /* optimizer/moving_average_optimizer.cc:39-47: w = momentum w + (1 - momentum) g, no state */
+  MONO_OPT_MOVING_AVERAGE = 9
 };
 enum { MONO_INIT_ZEROS = 0, MONO_INIT_ONES = 1, MONO_INIT_CONSTANT = 2, MONO_INIT_UNIFORM = 3 };
 

@@ -26,6 +26,7 @@ SGD, ADAGRAD, FTRL = entry.OPT_SGD, entry.OPT_ADAGRAD, entry.OPT_FTRL
 MOMENTUM, RMSPROP, RMSPROP_V2, ADADELTA = (entry.OPT_MOMENTUM, entry.OPT_RMSPROP,
                                            entry.OPT_RMSPROP_V2, entry.OPT_ADADELTA)
 ADAM, AMSGRAD = entry.OPT_ADAM, entry.OPT_AMSGRAD
+MOVING_AVERAGE = entry.OPT_MOVING_AVERAGE
 # SingleOptimizerDump oneof field (optimizer.proto:216-231) and, per optimizer, the dump's float
 # fields in SERIALIZATION order: (field number, state slot of the row | "scalar k").
 _DUMP_FIELDS = {
@@ -39,6 +40,9 @@ _DUMP_FIELDS = {
     # m, v (, vhat) per weight, then the row's beta1^t, beta2^t (optional float fields)
     ADAM: (7, [(1, 0), (2, 1), (3, "s0"), (4, "s1")]),
     AMSGRAD: (8, [(1, 0), (2, 1), (3, 2), (4, "s0"), (5, "s1")]),
+    # moving_average_optimizer.cc:49-52: Save() returns an OptimizerDump without entries, so the
+    # segment contributes NO SingleOptimizerDump (optimizer_combination.cc:65-75 concatenates)
+    MOVING_AVERAGE: (None, []),
 }
 
 
@@ -162,6 +166,8 @@ class DumpLayout:
       body = bytearray()
       marks = []
       field, parts, nfloats = _dump_parts(k, d)
+      if field is None:
+        continue
       for fno, off, cnt in parts:  # ascending field numbers = serialization order
         for i in range(cnt):
           body.append((fno << 3) | 5)
@@ -331,11 +337,12 @@ class DumpLayout:
       if tag >> 3 == 1:
         singles.append(opt[pos:pos + n])
       pos += n
-    if len(singles) != len(self.segments):
-      raise ValueError("EntryDump of id %d has %d optimizer dumps, the table has %d segments" %
-                       (rid, len(singles), len(self.segments)))
+    dumping = [(d, k) for d, k in self.segments if _DUMP_FIELDS[k][0] is not None]
+    if len(singles) != len(dumping):
+      raise ValueError("EntryDump of id %d has %d optimizer dumps, the table has %d dumping "
+                       "segments" % (rid, len(singles), len(dumping)))
     st = self.dim
-    for (d, k), single in zip(self.segments, singles):
+    for (d, k), single in zip(dumping, singles):
       tag, p2 = _read_varint(single, 0) if single else (0, 0)
       n, p2 = _read_varint(single, p2) if single else (0, 0)
       body = single[p2:p2 + n]

@@ -53,7 +53,7 @@ struct SegDev {
 // m | v (| vhat)
 __host__ __device__ inline int opt_nstate(int kind) {
   switch (kind) {
-    case MONO_OPT_SGD: return 0;
+    case MONO_OPT_SGD: case MONO_OPT_MOVING_AVERAGE: return 0;
     case MONO_OPT_FTRL: case MONO_OPT_ADADELTA: case MONO_OPT_ADAM: return 2;
     case MONO_OPT_AMSGRAD: return 3;
     default: return 1;
@@ -561,6 +561,8 @@ __device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, fl
     s1 = new_v;
     x.b1p *= c.beta1;  // every lane keeps its own copy: one multiplication per Optimize call
     x.b2p *= c.beta2;
+  } else if (kind == MONO_OPT_MOVING_AVERAGE) {  // moving_average_optimizer.cc:43-46
+    w = c.momentum * w + (1 - c.momentum) * g;
   } else {  // adadelta_optimizer.cc:50-66; s0 = accum, s1 = accum_update
     const float cur = g + c.wd * w;
     const float new_accum = s0 * c.rho + cur * cur * (1 - c.rho);
@@ -1641,7 +1643,7 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
   int w = 0;
   for (int s = 0; s < cfg->n_segments; ++s) {
     const mono_segment_cfg& c = cfg->segments[s];
-    if (c.dim <= 0 || c.opt_kind < 0 || c.opt_kind > MONO_OPT_AMSGRAD || c.init_kind < 0 ||
+    if (c.dim <= 0 || c.opt_kind < 0 || c.opt_kind > MONO_OPT_MOVING_AVERAGE || c.init_kind < 0 ||
         c.init_kind > MONO_INIT_UNIFORM) {
       delete t;
       return fail("mono_table_create: bad segment %d (dim %d opt %d init %d)", s, c.dim,

@@ -10,6 +10,7 @@ from typing import Any, Callable, Dict, List, Optional, Union
 OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_RMSPROP, OPT_RMSPROP_V2, OPT_ADADELTA = 3, 4, 5, 6
 OPT_ADAM, OPT_AMSGRAD = 7, 8
+OPT_MOVING_AVERAGE = 9
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT, INIT_UNIFORM = 0, 1, 2, 3
 
 
@@ -105,6 +106,30 @@ class AmsgradOptimizer(Optimizer):  # entry.py:175-222, optimizer.proto:123-132
   epsilon: float = 0.01
   warmup_steps: int = 0
   kind = OPT_AMSGRAD
+
+
+@dataclasses.dataclass
+class MovingAverageOptimizer(Optimizer):  # entry.py:247-255, optimizer.proto:155-158
+  momentum: float = 0.9
+  kind = OPT_MOVING_AVERAGE
+
+
+class _NotImplementedOptimizer(Optimizer):
+  """Optimizers whose reference factory throws `optimizer is not implemented yet`
+  (group_ftrl_optimizer.cc:25-29, dynamic_wd_adagrad_optimizer.cc:25-29): a table built with one
+  fails the same way here (hash_table_ops raises ValueError with the reference's text)."""
+  kind = None
+
+  def __init__(self, **kwargs):
+    self.__dict__.update(kwargs)
+
+
+class FTRLWithGroupSparsityOptimizer(_NotImplementedOptimizer):  # entry.py:286-306
+  pass
+
+
+class DynamicWdAdagradOptimizer(_NotImplementedOptimizer):  # entry.py:312-338
+  pass
 
 
 class Initializer:

@@ -81,12 +81,14 @@ class _TableResource:
   def __init__(self, table_config: entry.EmbeddingHashTableConfig,
                hash_filter: hash_filter_ops.HashFilter):
     segs = []
+    _reject_unimplemented_optimizers(table_config)
     for s in table_config.segments:
       o, i = s.opt_config, s.init_config
       if not isinstance(o, (entry.SgdOptimizer, entry.AdagradOptimizer, entry.FtrlOptimizer,
                             entry.MomentumOptimizer, entry.RmspropOptimizer,
                             entry.RmspropV2Optimizer, entry.AdadeltaOptimizer,
-                            entry.AdamOptimizer, entry.AmsgradOptimizer)):
+                            entry.AdamOptimizer, entry.AmsgradOptimizer,
+                            entry.MovingAverageOptimizer)):
         raise ValueError("optimizer %r is out of scope of the MI355X hot path" % (o,))
       init_acc = getattr(o, "initial_accumulator_value", None)
       seg = _lib.SegCfg(
@@ -445,6 +447,14 @@ def fused_apply_gradient(tables: List, ids, fused_slot_size, id_grads, id_offset
   return tables
 
 
+def _reject_unimplemented_optimizers(table_config):
+  """optimizer_factory.cc:50-53,76-78: the reference factory throws for these configs."""
+  for s in table_config.segments:
+    o = s.opt_config
+    if isinstance(o, entry._NotImplementedOptimizer):
+      raise ValueError("optimizer is not implemented yet. %s %r" % (type(o).__name__, o.__dict__))
+
+
 def hash_table_from_config(config: entry.HashTableConfigInstance,
                            hash_filter: Optional[hash_filter_ops.HashFilter] = None,
                            name_suffix="", sync_client=None, saver_parallel: int = -1) -> HashTable:
@@ -452,6 +462,7 @@ def hash_table_from_config(config: entry.HashTableConfigInstance,
   table_config = config.table_config
   dim_size = table_config.dim_size
   hash_table_name = "MonolithHashTable_" + name_suffix
+  _reject_unimplemented_optimizers(table_config)
   if hash_filter is None:
     hash_filter = hash_filter_ops.create_dummy_hash_filter(name_suffix=name_suffix)
   if len(config.learning_rate_fns) != len(table_config.segments):

@@ -30,7 +30,8 @@
 namespace {
 
 enum { OPT_SGD = 0, OPT_ADAGRAD = 1, OPT_FTRL = 2, OPT_MOMENTUM = 3, OPT_RMSPROP = 4,
-       OPT_RMSPROP_V2 = 5, OPT_ADADELTA = 6, OPT_ADAM = 7, OPT_AMSGRAD = 8 };
+       OPT_RMSPROP_V2 = 5, OPT_ADADELTA = 6, OPT_ADAM = 7, OPT_AMSGRAD = 8,
+       OPT_MOVING_AVERAGE = 9 };
 enum { INIT_ZEROS = 0, INIT_ONES = 1, INIT_CONSTANT = 2, INIT_UNIFORM = 3 };
 
 struct SegCfg {  // == mono_segment_cfg
@@ -49,7 +50,7 @@ struct SegCfg {  // == mono_segment_cfg
 // floats of optimizer context: SizeBytes() / sizeof(float) of the reference optimizers
 inline int state_floats(int kind, int dim) {
   switch (kind) {
-    case OPT_SGD: return 0;
+    case OPT_SGD: case OPT_MOVING_AVERAGE: return 0;  // moving_average_optimizer.cc:29-31
     case OPT_FTRL: case OPT_ADADELTA: return 2 * dim;
     case OPT_ADAM: return 2 * dim + 2;     // adam_optimizer.cc:29-31: m | v | beta1^t | beta2^t
     case OPT_AMSGRAD: return 3 * dim + 2;  // amsgrad_optimizer.cc: m | v | vhat | powers
@@ -382,6 +383,11 @@ struct Table {
         }
         beta1_power *= c.beta1;
         beta2_power *= c.beta2;
+      } else if (c.opt_kind == OPT_MOVING_AVERAGE) {  // moving_average_optimizer.cc:39-47
+        for (int i = 0; i < c.dim; ++i) {
+          float new_w = c.momentum * num[i] + (1 - c.momentum) * g[i];
+          num[i] = new_w;
+        }
       } else if (c.opt_kind == OPT_ADADELTA) {  // adadelta_optimizer.cc:50-66
         float* accum = st;
         float* accum_update = st + c.dim;

@@ -29,6 +29,8 @@ def _opt(d):
     return cls(beta1=d.get("beta1", 0.9), beta2=d.get("beta2", 0.99),
                weight_decay_factor=d.get("weight_decay", 0.0),
                use_nesterov=d.get("use_nesterov", False), epsilon=d.get("epsilon", 0.01))
+  if k == "moving_average":
+    return entry.MovingAverageOptimizer(momentum=d.get("momentum", 0.9))
   if k == "adadelta":
     return entry.AdadeltaOptimizer(weight_decay_factor=d.get("weight_decay", 0.0),
                                    averaging_ratio=d.get("averaging_ratio", 0.9),

@@ -1,4 +1,4 @@
-"""Momentum, RMSProp, RMSPropV2, Adadelta.
+"""Momentum, RMSProp, RMSPropV2, Adadelta, Adam, AMSGrad, MovingAverage.
 
 CPU: the oracle against the reference's unit-test vectors (momentum_optimizer_test.cc:32-70,
 rmsprop_optimizer_test.cc:32-70, adadelta_optimizer_test.cc:32-70; FloatNear 1e-6 there too).
@@ -66,6 +66,56 @@ def test_adam_amsgrad_reference_vectors():
     assert np.allclose(r[1][-2:], [0.9 ** 3, 0.99 ** 3], rtol=1e-6)
 
 
+def test_moving_average_reference_vectors():
+  """moving_average_optimizer_test.cc:32-73 (FloatNear 1e-6): no state, momentum 0.9."""
+  r = _steps("moving_average", 1, [[10.0], [10.0]])
+  assert len(r[0]) == 1 and abs(r[0][0] - 1.0) < 1e-6 and abs(r[1][0] - 1.9) < 1e-6
+  r = _steps("moving_average", 2, [[10.0, 1.0], [10.0, 1.0]])
+  assert np.allclose(r[0], [1.0, 0.1], atol=1e-6) and np.allclose(r[1], [1.9, 0.19], atol=1e-6)
+
+
+def test_moving_average_segment_has_no_optimizer_dump():
+  """moving_average_optimizer.cc:49-52 saves an OptimizerDump without entries: in a combined
+  entry the segment contributes nothing to EntryDump.opt.dump (optimizer_combination.cc:65-75)."""
+  import struct
+  from monolith_amd import checkpoint as ck
+  layout = ck.DumpLayout([(1, ck.MOVING_AVERAGE), (1, ck.ADAGRAD), (2, ck.MOVING_AVERAGE)])
+  assert layout.row_floats == 4 + 1
+  rows = np.array([[1.5, 2.5, 3.5, 4.5, 0.75]], np.float32)
+  (rec,) = layout.encode(np.array([11], np.int64), rows, np.array([5], np.uint32))
+  f = lambda *xs: b"".join(bytes([t]) + struct.pack("<f", v) for t, v in xs)
+  ada = f((0x0d, 0.75))
+  single = bytes([(1 << 3) | 2, len(ada)]) + ada
+  opt = bytes([0x0a, len(single)]) + single
+  exp = b"\x09" + struct.pack("<q", 11) + f((0x15, 1.5), (0x15, 2.5), (0x15, 3.5), (0x15, 4.5)) + \
+      bytes([0x1a, len(opt)]) + opt + b"\x20\x05"
+  assert rec[0].tobytes() == exp
+  rid, row, ts = layout._decode_one(exp)
+  assert rid == 11 and ts == 5 and np.array_equal(row, rows[0])
+  # a table of moving averages only: opt is present and empty
+  only = ck.DumpLayout([(2, ck.MOVING_AVERAGE)])
+  (rec,) = only.encode(np.array([1], np.int64), np.array([[1.0, 2.0]], np.float32), np.array([1], np.uint32))
+  assert rec[0].tobytes() == b"\x09" + struct.pack("<q", 1) + f((0x15, 1.0), (0x15, 2.0)) + b"\x1a\x00\x20\x01"
+  ids, rr, tt = only.decode(rec[0], np.array([0]), np.array([rec.shape[1]]))
+  assert ids[0] == 1 and np.array_equal(rr[0], [1.0, 2.0]) and tt[0] == 1
+
+
+def test_unimplemented_optimizers_fail_like_the_reference():
+  """group_ftrl_optimizer.cc:25-29 / dynamic_wd_adagrad_optimizer.cc:25-29 throw
+  `optimizer is not implemented yet`; the error is raised before any device work."""
+  from monolith_amd import entry
+  for opt in (entry.FTRLWithGroupSparsityOptimizer(learning_rate=0.1, beta=1.0),
+              entry.DynamicWdAdagradOptimizer(learning_rate=0.1)):
+    tc = entry.EmbeddingHashTableConfig(
+        segments=[entry.CombineAsSegment(2, entry.ZerosInitializer(), opt)])
+    try:
+      from monolith_amd import hash_table_ops
+    except ImportError:
+      pytest.skip("library not built")
+    with pytest.raises(ValueError, match="optimizer is not implemented yet"):
+      hash_table_ops.hash_table_from_config(entry.HashTableConfigInstance(tc, [0.1]))
+
+
 def test_dump_layout_of_new_optimizers_matches_protobuf_field_numbers():
   """optimizer.proto:216-231: adadelta = 6 {accum 1, accum_update 2}, momentum = 9 {n 1},
   rmsprop = 11 {n 1}, rmspropv2 = 12 {n 1}."""
@@ -112,6 +162,11 @@ CASES = {
     "mixed_adam": {"segments": [{"dim": 2, "opt": "adam"}, {"dim": 3, "opt": "adagrad"},
                                 {"dim": 2, "opt": "amsgrad", "use_nesterov": True},
                                 {"dim": 1, "opt": "ftrl", "beta": 1.0}, {"dim": 4, "opt": "adam"}]},
+    "moving_average": {"segments": [{"dim": 16, "opt": "moving_average", "momentum": 0.7,
+                                     "init": "uniform", "init_a": -0.1, "init_b": 0.1}]},
+    "mixed_ma": {"segments": [{"dim": 3, "opt": "moving_average"}, {"dim": 2, "opt": "adam"},
+                              {"dim": 1, "opt": "moving_average", "momentum": 0.5},
+                              {"dim": 2, "opt": "adagrad"}]},
     "mixed": {"segments": [{"dim": 1, "opt": "ftrl", "init_acc": 0.1, "beta": 1.0},
                            {"dim": 3, "opt": "adadelta"}, {"dim": 4, "opt": "momentum"},
                            {"dim": 2, "opt": "rmsprop"}, {"dim": 6, "opt": "adagrad"},
@@ -166,6 +221,17 @@ def test_new_optimizer_tables_save_and_restore(tmp_path):
                           y.view(np.uint32) if y.dtype == np.float32 else y)
   layout = ck.DumpLayout.from_table_config(hip_backend.table_config(cfg))
   assert layout.row_floats == h.row_floats == 20 + 2 + 6 + 4 + 2 + 6 + 2
+  # a segment without optimizer dump between dumping ones
+  cfg = CASES["mixed_ma"]
+  h = hip_backend.make_table(cfg)
+  h.apply_gradients(ids, rng.normal(0, 1, (500, 8)).astype(np.float32), [0.01] * 4, req_time=78)
+  base = str(tmp_path / "ma")
+  h.t.save(base)
+  h2 = hip_backend.make_table(cfg)
+  h2.t = h2.t.restore(base)
+  for x, y in zip(h.export(), h2.export()):
+    assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x,
+                          y.view(np.uint32) if y.dtype == np.float32 else y)
 
 
 def test_adam_dump_bytes():
