@@ -255,13 +255,14 @@ __device__ __forceinline__ unsigned long long lb_load(const uint32_t* row, int l
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned long long lb_wait(unsigned long long v, const uint32_t* row,
-                                                      int l2, uint32_t* err) {
+                                                      int l2, uint32_t* err, int* timed_out) {
   const unsigned long long both = ((unsigned long long)kRowReady << 32) | kRowReady;
   uint32_t spins = 0;
   while ((v & both) != both) {
     __builtin_amdgcn_s_sleep(2);
     if (++spins > kSpinLimit) {
       atomicExch(err, 1u);
+      *timed_out = 1;
       break;
     }
     v = lb_load(row, l2);
@@ -293,9 +294,13 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
   uint32_t* const sv = stage + kSortTile;
   unsigned long long* const match = reinterpret_cast<unsigned long long*>(stage);
   __shared__ uint32_t s_tile;
+  __shared__ int s_timed_out;
   const int nd = 1 << bits;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  if (threadIdx.x == 0) {
+    s_tile = atomicAdd(ticket, 1u);
+    s_timed_out = 0;
+  }
   for (int i = threadIdx.x; i < kSortWaves * kSortMaxDigits; i += kSortThreads) {
     (&cnt[0][0])[i] = 0;
     match[i] = 0ull;
@@ -303,6 +308,10 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
   for (int i = threadIdx.x; i < kSortMaxDigits; i += kSortThreads) nh[i] = 0;
   __syncthreads();
   const int tile = (int)s_tile;
+  if (tile >= tiles) {  // a ticket word that did not start at zero: never index past the rows
+    if (threadIdx.x == 0) atomicExch(err, 2u);
+    return;
+  }
   const int64_t tile0 = (int64_t)tile * kSortTile;
   const int64_t base = tile0 + (int64_t)w * (64 * kSortItems);
   uint32_t key[kSortItems], val[kSortItems], rank[kSortItems];
@@ -348,6 +357,7 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
   // every tile before it. Smaller tickets are already running and publish before they wait, and
   // a group total waits on tile rows only: every wait ends. Four sets of 128 threads split the
   // rows; a thread reads two digits per 8-byte load, all its loads of a level in flight.
+  int timed_out = 0;
   {
     const int set = threadIdx.x >> 7, l2 = threadIdx.x & 127;
     const int g = tile / kLbGroup, g0 = g * kLbGroup;
@@ -364,7 +374,7 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
       for (int u = 0; u < kLbGroup / 4; ++u) {
         const int t = g0 + set + 4 * u;
         if (t < tile) {
-          v[u] = lb_wait(v[u], rows + (size_t)t * kSortMaxDigits, l2, err);
+          v[u] = lb_wait(v[u], rows + (size_t)t * kSortMaxDigits, l2, err, &timed_out);
           sum0 += (uint32_t)v[u] & ~kRowReady;
           sum1 += (uint32_t)(v[u] >> 32) & ~kRowReady;
         }
@@ -390,7 +400,7 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
       for (int u = 0; u < kLbMaxGroups / 4; ++u) {
         const int gg = set + 4 * u;
         if (gg < g) {
-          v[u] = lb_wait(v[u], grows + (size_t)gg * kSortMaxDigits, l2, err);
+          v[u] = lb_wait(v[u], grows + (size_t)gg * kSortMaxDigits, l2, err, &timed_out);
           sum0 += (uint32_t)v[u] & ~kRowReady;
           sum1 += (uint32_t)(v[u] >> 32) & ~kRowReady;
         }
@@ -399,7 +409,11 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
     tpre[set][2 * l2] = sum0;
     tpre[set][2 * l2 + 1] = sum1;
   }
+  if (timed_out) s_timed_out = 1;
   __syncthreads();
+  // a wait gave up (error word raised, mono_debug_sort_error): the sums are not to be trusted,
+  // so this tile writes nothing rather than somewhere
+  if (s_timed_out) return;
   if (next_bits > 0)
     for (int i = threadIdx.x; i < (1 << next_bits); i += kSortThreads)
       if (nh[i]) atomicAdd(&dhist_next[i], nh[i]);
