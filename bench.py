@@ -344,7 +344,7 @@ def main():
   # separate rocprofv3 --pmc runs of this same command; calibration note in the summary file)
   traffic, traffic_src = None, None
   try:
-    with open(os.path.join(ROOT, "profiles", "r01_f_pmc_summary.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r01_g_pmc_summary.json")) as f:
       pmc = json.load(f)["kernels"]
     members = {"k_lookup": ["mono::k_lookup<4>"], "k_claim_pending": ["mono::k_claim_pending"],
                "k_apply": ["mono::k_classify", "mono::k_apply<2, 1>", "mono::k_apply_long<1, 3>",
@@ -352,7 +352,7 @@ def main():
     if args.batch == 65536 and args.rows == 1e8 and args.skew == 3.0:
       traffic = sum((pmc[m]["FETCH_SIZE_KB_last_launch"] + pmc[m]["WRITE_SIZE_KB_last_launch"]) *
                     1024.0 for m in members)
-      traffic_src = "profiles/r01_f_pmc_summary.json (" + " + ".join(members) + ")"
+      traffic_src = "profiles/r01_g_pmc_summary.json (" + " + ".join(members) + ")"
   except (OSError, KeyError, ValueError):
     pass
 
