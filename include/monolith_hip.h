@@ -34,7 +34,10 @@ enum {
   /* optimizer/{adam,amsgrad}_optimizer.cc: m | v (| vhat) per weight + beta1^t, beta2^t per row */
   MONO_OPT_ADAM = 7, MONO_OPT_AMSGRAD = 8,
   /* optimizer/moving_average_optimizer.cc:39-47: w = momentum w + (1 - momentum) g, no state */
-  MONO_OPT_MOVING_AVERAGE = 9
+  MONO_OPT_MOVING_AVERAGE = 9,
+  /* optimizer/batch_softmax_optimizer.cc:42-54: dim 1; w = (1 - lr) w + lr (global_step - A),
+   * A = global_step; A is an int64 kept in the segment's two state floats (low | high word) */
+  MONO_OPT_BATCH_SOFTMAX = 10
 };
 enum { MONO_INIT_ZEROS = 0, MONO_INIT_ONES = 1, MONO_INIT_CONSTANT = 2, MONO_INIT_UNIFORM = 3 };
 

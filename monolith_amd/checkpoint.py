@@ -27,6 +27,7 @@ MOMENTUM, RMSPROP, RMSPROP_V2, ADADELTA = (entry.OPT_MOMENTUM, entry.OPT_RMSPROP
                                            entry.OPT_RMSPROP_V2, entry.OPT_ADADELTA)
 ADAM, AMSGRAD = entry.OPT_ADAM, entry.OPT_AMSGRAD
 MOVING_AVERAGE = entry.OPT_MOVING_AVERAGE
+BATCH_SOFTMAX = entry.OPT_BATCH_SOFTMAX
 # SingleOptimizerDump oneof field (optimizer.proto:216-231) and, per optimizer, the dump's float
 # fields in SERIALIZATION order: (field number, state slot of the row | "scalar k").
 _DUMP_FIELDS = {
@@ -43,7 +44,13 @@ _DUMP_FIELDS = {
     # moving_average_optimizer.cc:49-52: Save() returns an OptimizerDump without entries, so the
     # segment contributes NO SingleOptimizerDump (optimizer_combination.cc:65-75 concatenates)
     MOVING_AVERAGE: (None, []),
+    # BatchSoftmaxOptimizerDump = 14 {optional int64 global_step = 1}: a varint, see _INT64_PART
+    BATCH_SOFTMAX: (14, []),
 }
+# optimizers whose state is one int64 (two state floats, low word first) dumped as a varint field:
+# records of such tables have no fixed layout and are converted one by one
+_INT64_PART = {BATCH_SOFTMAX: 1}
+
 
 
 def _dump_parts(kind: int, d: int):
@@ -57,7 +64,7 @@ def _dump_parts(kind: int, d: int):
       out.append((fno, nslots * d + int(where[1:]), 1))
     else:
       out.append((fno, where * d, d))
-  return field, out, sum(c for _, _, c in out)
+  return field, out, sum(c for _, _, c in out) + (2 if kind in _INT64_PART else 0)
 
 
 def sharded_name(basename: str, idx: int, total: int) -> str:
@@ -143,6 +150,7 @@ class DumpLayout:
     self.dim = sum(d for d, _ in self.segments)
     self.state = sum(_opt_payload_len(k, d) // 5 for d, k in self.segments)
     self.row_floats = self.dim + self.state
+    self.irregular = any(k in _INT64_PART for _, k in self.segments)
 
   @staticmethod
   def from_table_config(tc: entry.EmbeddingHashTableConfig) -> "DumpLayout":
@@ -202,6 +210,11 @@ class DumpLayout:
     ids = np.asarray(ids, np.int64)
     rows = np.ascontiguousarray(rows, np.float32).reshape(len(ids), self.row_floats)
     ts = np.asarray(ts).astype(np.uint64)
+    if self.irregular:
+      recs = [self._encode_one(int(ids[i]), rows[i], int(ts[i])) for i in range(len(ids))]
+      lens = np.array([len(r) for r in recs], np.int64)
+      return [np.frombuffer(b"".join(recs[i] for i in np.nonzero(lens == L)[0]), np.uint8)
+              .reshape(-1, int(L)) for L in np.unique(lens)]
     vlen = np.ones(len(ids), np.int64)
     for k in range(1, 10):
       vlen += (ts >= (1 << (7 * k))).astype(np.int64)
@@ -233,7 +246,7 @@ class DumpLayout:
     rows = np.zeros((n, self.row_floats), np.float32)
     ts = np.zeros(n, np.uint32)
     done = np.zeros(n, bool)
-    for ts_len in range(1, 6):
+    for ts_len in (() if self.irregular else range(1, 6)):
       tmpl, id_off, f_offs, ts_off = self._template(ts_len)
       sel = np.nonzero((ln == len(tmpl)) & ~done)[0]
       if not len(sel):
@@ -263,14 +276,40 @@ class DumpLayout:
       ids[i], rows[i], ts[i] = self._decode_one(buf[off[i]:off[i] + ln[i]])
     return ids, rows, ts
 
+  def _encode_one(self, rid: int, row: np.ndarray, ts: int) -> bytes:
+    """One EntryDump, field by field (tables with a varint optimizer field)."""
+    import struct
+    row = np.ascontiguousarray(row, np.float32)
+    b = b"\x09" + struct.pack("<q", rid)
+    b += b"".join(b"\x15" + row[i:i + 1].tobytes() for i in range(self.dim))
+    opt = b""
+    st = self.dim
+    for d, k in self.segments:
+      field, parts, nfloats = _dump_parts(k, d)
+      if field is not None:
+        body = b""
+        if k in _INT64_PART:
+          a = int(row[st:st + 2].view(np.int64)[0])
+          body += bytes([(_INT64_PART[k] << 3) | 0]) + _varint(a & 0xFFFFFFFFFFFFFFFF)
+        for fno, off, cnt in parts:
+          body += b"".join(bytes([(fno << 3) | 5]) + row[st + off + i:st + off + i + 1].tobytes()
+                           for i in range(cnt))
+        single = _len_prefixed((field << 3) | 2, len(body)) + body
+        opt += _len_prefixed(0x0a, len(single)) + single
+      st += nfloats
+    return b + _len_prefixed(0x1a, len(opt)) + opt + b"\x20" + _varint(ts)
+
   def _decode_one(self, b):
     """Generic EntryDump parse of one record (any field order, packed or unpacked floats)."""
     import struct
     b = bytes(b)
     rid, nums, opt, ts = 0, [], b"", 0
 
+    ints: Dict[int, int] = {}
+
     def floats(body, want_fields):
       res: Dict[int, List[float]] = {f: [] for f in want_fields}
+      ints.clear()
       pos = 0
       while pos < len(body):
         tag, pos = _read_varint(body, pos)
@@ -286,7 +325,7 @@ class DumpLayout:
             res[f].extend(struct.unpack_from("<%df" % (n // 4), body, pos))
           pos += n
         elif wt == 0:
-          _, pos = _read_varint(body, pos)
+          ints[f], pos = _read_varint(body, pos)
         elif wt == 1:
           pos += 8
         else:
@@ -352,6 +391,9 @@ class DumpLayout:
         raise ValueError("segment expects optimizer dump field %d, found field %d" %
                          (field, kind_field))
       r = floats(body, [fno for fno, _, _ in parts])
+      if k in _INT64_PART:  # an absent field reads as 0, like the proto2 getter
+        a = ints.get(_INT64_PART[k], 0) & 0xFFFFFFFFFFFFFFFF
+        row[st:st + 2] = np.array([a], np.uint64).view(np.float32)
       for fno, off, cnt in parts:
         if len(r[fno]) != cnt:
           raise ValueError("optimizer dump field %d has %d values, expected %d" %

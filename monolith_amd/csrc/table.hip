@@ -54,7 +54,8 @@ struct SegDev {
 __host__ __device__ inline int opt_nstate(int kind) {
   switch (kind) {
     case MONO_OPT_SGD: case MONO_OPT_MOVING_AVERAGE: return 0;
-    case MONO_OPT_FTRL: case MONO_OPT_ADADELTA: case MONO_OPT_ADAM: return 2;
+    case MONO_OPT_FTRL: case MONO_OPT_ADADELTA: case MONO_OPT_ADAM:
+    case MONO_OPT_BATCH_SOFTMAX: return 2;  // one int64 (dim is 1)
     case MONO_OPT_AMSGRAD: return 3;
     default: return 1;
   }
@@ -450,6 +451,7 @@ struct ApplyArgs {
   float lr[kMaxSeg];
   FilterDev filt;  // from_keys only; filt.kind == 0 -> no gate
   int assign_add_semantics;  // filter gate of the per-id AssignAdd loop (bridge :186-209)
+  long long global_step;     // Optimize()'s global_step (batch softmax reads it)
   struct LongSeg* queue;     // segments longer than kLongSeg, drained by k_apply_long
   uint32_t* qcount;          // [0] queue entries [1] compacted heads [2] split keys [3] partial rows
                              // [4] next queue entry to hand out (k_apply_long)
@@ -505,6 +507,7 @@ __device__ inline int64_t segment_end(const K* keys, int64_t j, int64_t n, K key
 // third state slot + per-row scalars (generic path only; the specialised kernels pass a dummy)
 struct OptX {
   float s2 = 0.f, b1p = 0.f, b2p = 0.f;
+  long long gstep = 0;  // the call's global_step (batch softmax)
 };
 
 __device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, float g, float& w,
@@ -561,6 +564,12 @@ __device__ __forceinline__ void opt_step(int kind, const SegDev& c, float lr, fl
     s1 = new_v;
     x.b1p *= c.beta1;  // every lane keeps its own copy: one multiplication per Optimize call
     x.b2p *= c.beta2;
+  } else if (kind == MONO_OPT_BATCH_SOFTMAX) {  // batch_softmax_optimizer.cc:42-54; g unused
+    const long long A = (long long)(((unsigned long long)__float_as_uint(s1) << 32) |
+                                    (unsigned long long)__float_as_uint(s0));
+    w = (1 - lr) * w + lr * (float)(x.gstep - A);
+    s0 = __uint_as_float((uint32_t)((unsigned long long)x.gstep & 0xFFFFFFFFull));
+    s1 = __uint_as_float((uint32_t)((unsigned long long)x.gstep >> 32));
   } else if (kind == MONO_OPT_MOVING_AVERAGE) {  // moving_average_optimizer.cc:43-46
     w = c.momentum * w + (1 - c.momentum) * g;
   } else {  // adadelta_optimizer.cc:50-66; s0 = accum, s1 = accum_update
@@ -732,6 +741,8 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
     if (e0 >= D) continue;
     float w[V], s0[V], s1[V];
     OptX ox[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) ox[q].gstep = a.global_step;
     int kind[V];
     int segi[V];
     int st0_off[V], st1_off[V];
@@ -954,6 +965,7 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
       }
       float w = 0.f, s0 = 0.f, s1 = 0.f, acc = 0.f;
       OptX ox;
+      ox.gstep = a.global_step;
       bool have_acc = false;
       const bool need_state = MODE >= MODE_OPT_SEQ;
       const bool part = ls.part != kNoPart;  // one chunk of a split key: emit the chunk sum only
@@ -1138,6 +1150,7 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
       const bool need_state = a.mode >= MODE_OPT_SEQ;
       float w, s0 = 0.f, s1 = 0.f;
       OptX ox;
+      ox.gstep = a.global_step;
       if (OPTK == OPTK_MULTI && (need_state || sp.fresh))
         optx_load(t, t.seg[segi], row, e, sp.fresh != 0, sp.key, ox);
       if (sp.fresh) {
@@ -1510,7 +1523,8 @@ static int bits_for(uint64_t max_value) {
 // The whole write path. `filter` gates inserts of unknown ids (nullptr / dummy = no gate).
 static int write_path(Table* t, void* filter, const int64_t* ids, const float* src,
                       const uint32_t* src_ts, int64_t n, int mode, const float* lrs, int n_lrs,
-                      int64_t req_time, int assign_add_semantics, hipStream_t st) {
+                      int64_t req_time, int assign_add_semantics, hipStream_t st,
+                      int64_t global_step = 0) {
   if (n == 0) return 0;
   MONO_REQUIRE(n < (int64_t)0xFFFFFFF0ll, "batch of %lld ids exceeds the 32-bit index range",
                (long long)n);
@@ -1528,6 +1542,7 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   a.ts = (uint32_t)req_time;
   a.filt = fd;
   a.assign_add_semantics = assign_add_semantics;
+  a.global_step = global_step;
   for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
 
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
@@ -1643,8 +1658,9 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
   int w = 0;
   for (int s = 0; s < cfg->n_segments; ++s) {
     const mono_segment_cfg& c = cfg->segments[s];
-    if (c.dim <= 0 || c.opt_kind < 0 || c.opt_kind > MONO_OPT_MOVING_AVERAGE || c.init_kind < 0 ||
-        c.init_kind > MONO_INIT_UNIFORM) {
+    if (c.dim <= 0 || c.opt_kind < 0 || c.opt_kind > MONO_OPT_BATCH_SOFTMAX || c.init_kind < 0 ||
+        c.init_kind > MONO_INIT_UNIFORM ||
+        (c.opt_kind == MONO_OPT_BATCH_SOFTMAX && c.dim != 1)) {  // DCHECK_EQ(dim_size, 1)
       delete t;
       return fail("mono_table_create: bad segment %d (dim %d opt %d init %d)", s, c.dim,
                   c.opt_kind, c.init_kind);
@@ -1801,15 +1817,18 @@ int mono_table_apply_gradients(void* table, void* filter, const int64_t* ids, co
                                int64_t n, const float* h_learning_rates, int n_learning_rates,
                                int64_t req_time, int64_t global_step, int enable_dedup,
                                void* stream) {
-  (void)global_step;
   MONO_REQUIRE(table, "mono_table_apply_gradients: null table");
   Table* t = (Table*)table;
+  for (int s = 0; s < t->d.n_seg; ++s)  // batch_softmax_optimizer.cc:49-52 (LOG(FATAL) there)
+    MONO_REQUIRE(t->d.seg[s].opt_kind != MONO_OPT_BATCH_SOFTMAX || global_step >= 0,
+                 "global_step=%lld is negative, please investigate!", (long long)global_step);
   MONO_REQUIRE(n_learning_rates == t->d.n_seg,
                "mono_table_apply_gradients: %d learning rates for %d segments", n_learning_rates,
                t->d.n_seg);
   t->max_update_ts = std::max(t->max_update_ts, req_time);
   return write_path(t, filter, ids, grads, nullptr, n, enable_dedup ? MODE_OPT_DEDUP : MODE_OPT_SEQ,
-                    h_learning_rates, n_learning_rates, req_time, 0, (hipStream_t)stream);
+                    h_learning_rates, n_learning_rates, req_time, 0, (hipStream_t)stream,
+                    global_step);
 }
 
 int mono_table_import(void* table, const int64_t* ids, const float* rows, const uint32_t* ts,

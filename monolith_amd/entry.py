@@ -11,6 +11,7 @@ OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_RMSPROP, OPT_RMSPROP_V2, OPT_ADADELTA = 3, 4, 5, 6
 OPT_ADAM, OPT_AMSGRAD = 7, 8
 OPT_MOVING_AVERAGE = 9
+OPT_BATCH_SOFTMAX = 10
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT, INIT_UNIFORM = 0, 1, 2, 3
 
 
@@ -112,6 +113,12 @@ class AmsgradOptimizer(Optimizer):  # entry.py:175-222, optimizer.proto:123-132
 class MovingAverageOptimizer(Optimizer):  # entry.py:247-255, optimizer.proto:155-158
   momentum: float = 0.9
   kind = OPT_MOVING_AVERAGE
+
+
+@dataclasses.dataclass
+class BatchSoftmaxOptimizer(Optimizer):  # entry.py:207-223, optimizer.proto:160-167 (dim 1)
+  learning_rate: Optional[Any] = None   # the kernel reads the call's learning rate, like the reference
+  kind = OPT_BATCH_SOFTMAX
 
 
 class _NotImplementedOptimizer(Optimizer):

@@ -88,7 +88,7 @@ class _TableResource:
                             entry.MomentumOptimizer, entry.RmspropOptimizer,
                             entry.RmspropV2Optimizer, entry.AdadeltaOptimizer,
                             entry.AdamOptimizer, entry.AmsgradOptimizer,
-                            entry.MovingAverageOptimizer)):
+                            entry.MovingAverageOptimizer, entry.BatchSoftmaxOptimizer)):
         raise ValueError("optimizer %r is out of scope of the MI355X hot path" % (o,))
       init_acc = getattr(o, "initial_accumulator_value", None)
       seg = _lib.SegCfg(

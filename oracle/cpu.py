@@ -16,6 +16,7 @@ OPT_SGD, OPT_ADAGRAD, OPT_FTRL = 0, 1, 2
 OPT_MOMENTUM, OPT_RMSPROP, OPT_RMSPROP_V2, OPT_ADADELTA = 3, 4, 5, 6
 OPT_ADAM, OPT_AMSGRAD = 7, 8
 OPT_MOVING_AVERAGE = 9
+OPT_BATCH_SOFTMAX = 10
 INIT_ZEROS, INIT_ONES, INIT_CONSTANT, INIT_UNIFORM = 0, 1, 2, 3
 
 
@@ -82,7 +83,8 @@ def seg(dim, opt="sgd", init="zeros", init_acc=0.1, weight_decay=0.0, l1=0.0, l2
         learning_rate=0.01, use_nesterov=False, beta1=0.9, beta2=0.99):
   ok = {"sgd": OPT_SGD, "adagrad": OPT_ADAGRAD, "ftrl": OPT_FTRL, "momentum": OPT_MOMENTUM,
         "rmsprop": OPT_RMSPROP, "rmspropv2": OPT_RMSPROP_V2, "adadelta": OPT_ADADELTA,
-        "adam": OPT_ADAM, "amsgrad": OPT_AMSGRAD, "moving_average": OPT_MOVING_AVERAGE}[opt]
+        "adam": OPT_ADAM, "amsgrad": OPT_AMSGRAD, "moving_average": OPT_MOVING_AVERAGE,
+        "batch_softmax": OPT_BATCH_SOFTMAX}[opt]
   ik = {"zeros": INIT_ZEROS, "ones": INIT_ONES, "constant": INIT_CONSTANT,
         "uniform": INIT_UNIFORM}[init]
   return SegCfg(dim, ok, init_acc, weight_decay, l1, l2, beta, ik, init_a, init_b, momentum,

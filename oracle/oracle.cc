@@ -31,7 +31,7 @@ namespace {
 
 enum { OPT_SGD = 0, OPT_ADAGRAD = 1, OPT_FTRL = 2, OPT_MOMENTUM = 3, OPT_RMSPROP = 4,
        OPT_RMSPROP_V2 = 5, OPT_ADADELTA = 6, OPT_ADAM = 7, OPT_AMSGRAD = 8,
-       OPT_MOVING_AVERAGE = 9 };
+       OPT_MOVING_AVERAGE = 9, OPT_BATCH_SOFTMAX = 10 };
 enum { INIT_ZEROS = 0, INIT_ONES = 1, INIT_CONSTANT = 2, INIT_UNIFORM = 3 };
 
 struct SegCfg {  // == mono_segment_cfg
@@ -52,6 +52,7 @@ inline int state_floats(int kind, int dim) {
   switch (kind) {
     case OPT_SGD: case OPT_MOVING_AVERAGE: return 0;  // moving_average_optimizer.cc:29-31
     case OPT_FTRL: case OPT_ADADELTA: return 2 * dim;
+    case OPT_BATCH_SOFTMAX: return 2;  // batch_softmax_optimizer.cc:31: one int64
     case OPT_ADAM: return 2 * dim + 2;     // adam_optimizer.cc:29-31: m | v | beta1^t | beta2^t
     case OPT_AMSGRAD: return 3 * dim + 2;  // amsgrad_optimizer.cc: m | v | vhat | powers
     default: return dim;
@@ -294,7 +295,7 @@ struct Table {
   }
 
   // entry_accessor.cc:163-171 -> optimizer_combination.cc:53-63 -> per-segment Optimize
-  void optimize(Entry& e, const float* grad, const float* lrs) const {
+  void optimize(Entry& e, const float* grad, const float* lrs, int64_t global_step) const {
     for (size_t s = 0; s < segs.size(); ++s) {
       const SegCfg& c = segs[s];
       float* num = e.row.data() + seg_w_off[s];
@@ -383,6 +384,14 @@ struct Table {
         }
         beta1_power *= c.beta1;
         beta2_power *= c.beta2;
+      } else if (c.opt_kind == OPT_BATCH_SOFTMAX) {  // batch_softmax_optimizer.cc:42-54
+        float& B = num[0];
+        int64_t A;
+        std::memcpy(&A, st, sizeof(A));
+        float alpha = lr;
+        B = (1 - alpha) * B + alpha * static_cast<float>(global_step - A);
+        A = global_step;
+        std::memcpy(st, &A, sizeof(A));
       } else if (c.opt_kind == OPT_MOVING_AVERAGE) {  // moving_average_optimizer.cc:39-47
         for (int i = 0; i < c.dim; ++i) {
           float new_w = c.momentum * num[i] + (1 - c.momentum) * g[i];
@@ -559,7 +568,6 @@ void orc_table_assign_add(void* tp, void* fp, const int64_t* ids, const float* v
 void orc_table_apply_gradients(void* tp, void* fp, const int64_t* ids, const float* grads,
                                int64_t n, const float* lrs, int64_t req_time, int64_t global_step,
                                int enable_dedup) {
-  (void)global_step;
   Table* t = (Table*)tp;
   Filter* f = (Filter*)fp;
   touch_max_ts(t, req_time);
@@ -603,7 +611,7 @@ void orc_table_apply_gradients(void* tp, void* fp, const int64_t* ids, const flo
   for (size_t k = 0; k < ids_after.size(); ++k) {  // cuckoo_embedding_hash_table.cc:198-216
     Entry& e = t->upsert(ids_after[k]);
     e.ts = (uint32_t)req_time;
-    t->optimize(e, grads_after[k], lrs);
+    t->optimize(e, grads_after[k], lrs, global_step);
   }
 }
 

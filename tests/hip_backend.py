@@ -31,6 +31,8 @@ def _opt(d):
                use_nesterov=d.get("use_nesterov", False), epsilon=d.get("epsilon", 0.01))
   if k == "moving_average":
     return entry.MovingAverageOptimizer(momentum=d.get("momentum", 0.9))
+  if k == "batch_softmax":
+    return entry.BatchSoftmaxOptimizer()
   if k == "adadelta":
     return entry.AdadeltaOptimizer(weight_decay_factor=d.get("weight_decay", 0.0),
                                    averaging_ratio=d.get("averaging_ratio", 0.9),

@@ -48,6 +48,7 @@ def classes():
                                     ("beta2_power", 5, F.TYPE_FLOAT, O, None)])
   for n in ("MomentumOptimizerDump", "RmspropOptimizerDump", "RmspropV2OptimizerDump"):
     _msg(fd, n, [("n", 1, F.TYPE_FLOAT, R, None)])
+  _msg(fd, "BatchSoftmaxOptimizerDump", [("global_step", 1, F.TYPE_INT64, O, None)])
   _msg(fd, "SingleOptimizerDump", [("adagrad", 1, F.TYPE_MESSAGE, O, "AdagradOptimizerDump"),
                                    ("sgd", 2, F.TYPE_MESSAGE, O, "SgdOptimizerDump"),
                                    ("ftrl", 3, F.TYPE_MESSAGE, O, "FtrlOptimizerDump"),
@@ -56,7 +57,9 @@ def classes():
                                    ("amsgrad", 8, F.TYPE_MESSAGE, O, "AmsgradOptimizerDump"),
                                    ("momentum", 9, F.TYPE_MESSAGE, O, "MomentumOptimizerDump"),
                                    ("rmsprop", 11, F.TYPE_MESSAGE, O, "RmspropOptimizerDump"),
-                                   ("rmspropv2", 12, F.TYPE_MESSAGE, O, "RmspropV2OptimizerDump")])
+                                   ("rmspropv2", 12, F.TYPE_MESSAGE, O, "RmspropV2OptimizerDump"),
+                                   ("batch_softmax", 14, F.TYPE_MESSAGE, O,
+                                    "BatchSoftmaxOptimizerDump")])
   _msg(fd, "OptimizerDump", [("dump", 1, F.TYPE_MESSAGE, R, "SingleOptimizerDump")])
   _msg(fd, "EntryDump", [("id", 1, F.TYPE_SFIXED64, O, None), ("num", 2, F.TYPE_FLOAT, R, None),
                          ("opt", 3, F.TYPE_MESSAGE, O, "OptimizerDump"),
@@ -84,8 +87,13 @@ def _entry_msg(cls, layout, rid, row, ts):
   cur = layout.dim
   m.opt.SetInParent()
   for d, kind in layout.segments:
+    if kind == ck.MOVING_AVERAGE:  # Save() returns no entry (moving_average_optimizer.cc:49-52)
+      continue
     s = m.opt.dump.add()
-    if kind == ck.ADAGRAD:
+    if kind == ck.BATCH_SOFTMAX:
+      s.batch_softmax.global_step = int(row[cur:cur + 2].view(np.int64)[0])
+      cur += 2
+    elif kind == ck.ADAGRAD:
       s.adagrad.norm.extend(float(x) for x in row[cur:cur + d])
       cur += d
     elif kind == ck.FTRL:  # row state order norm | zero (ftrl_optimizer.cc:38-45)
@@ -134,6 +142,39 @@ def test_entry_dump_encoder_equals_protobuf(classes):
   assert len(mine) == n
   for i in range(n):
     assert _entry_msg(classes, layout, ids[i], rows[i], ts[i]).SerializeToString() == mine[int(ids[i])]
+
+
+def test_varint_state_and_dumpless_segments_equal_protobuf(classes):
+  """Batch softmax keeps an int64 (varint field, negative values as ten bytes); a moving-average
+  segment adds no SingleOptimizerDump: records are built one by one and must still be byte-equal."""
+  layout = ck.DumpLayout([(1, ck.BATCH_SOFTMAX), (2, ck.MOVING_AVERAGE), (2, ck.ADAGRAD),
+                          (1, ck.BATCH_SOFTMAX)])
+  assert layout.irregular and layout.row_floats == 6 + 2 + 2 + 2
+  rng = np.random.Generator(np.random.PCG64(12))
+  n = 40
+  ids = rng.integers(-2**62, 2**62, n)
+  rows = rng.normal(0, 1, (n, layout.row_floats)).astype(np.float32)
+  steps = rng.choice([0, 1, 127, 128, 300, 2**31, 2**40 + 5, -1, -2**40], (n, 2)).astype(np.int64)
+  rows[:, 6:8] = steps[:, :1].copy().view(np.float32)
+  rows[:, 10:12] = steps[:, 1:].copy().view(np.float32)
+  ts = rng.choice([0, 5, 128, 1_700_000_000], n).astype(np.uint32)
+  recs = [r.tobytes() for grp in layout.encode(ids, rows, ts) for r in grp]
+  assert len(recs) == n
+  by_id = {}
+  for r in recs:
+    m = classes["EntryDump"]()
+    m.ParseFromString(r)
+    by_id[m.id] = r
+  for i in range(n):
+    assert _entry_msg(classes, layout, ids[i], rows[i], ts[i]).SerializeToString() == by_id[int(ids[i])]
+  buf = np.frombuffer(b"".join(recs), np.uint8)
+  ln = np.array([len(r) for r in recs])
+  off = np.concatenate([[0], np.cumsum(ln)[:-1]])
+  ids2, rows2, ts2 = layout.decode(buf, off, ln)
+  order = np.argsort(ids2)
+  o0 = np.argsort(ids)
+  assert np.array_equal(ids2[order], ids[o0]) and np.array_equal(ts2[order], ts[o0])
+  assert np.array_equal(rows2[order].view(np.uint32), rows[o0].view(np.uint32))
 
 
 def test_reference_dumps_parse_identically_with_protobuf(classes):

@@ -1,4 +1,4 @@
-"""Momentum, RMSProp, RMSPropV2, Adadelta, Adam, AMSGrad, MovingAverage.
+"""Momentum, RMSProp, RMSPropV2, Adadelta, Adam, AMSGrad, MovingAverage, BatchSoftmax.
 
 CPU: the oracle against the reference's unit-test vectors (momentum_optimizer_test.cc:32-70,
 rmsprop_optimizer_test.cc:32-70, adadelta_optimizer_test.cc:32-70; FloatNear 1e-6 there too).
@@ -72,6 +72,24 @@ def test_moving_average_reference_vectors():
   assert len(r[0]) == 1 and abs(r[0][0] - 1.0) < 1e-6 and abs(r[1][0] - 1.9) < 1e-6
   r = _steps("moving_average", 2, [[10.0, 1.0], [10.0, 1.0]])
   assert np.allclose(r[0], [1.0, 0.1], atol=1e-6) and np.allclose(r[1], [1.9, 0.19], atol=1e-6)
+
+
+def test_batch_softmax_reference_vector():
+  """batch_softmax_optimizer_test.cc:32-51: B = (1 - a) B + a (global_step - A), A = global_step;
+  the state is the int64 step of the last update."""
+  t = cpu.OracleTable([cpu.seg(1, "batch_softmax")])
+  ids = np.array([7], np.int64)
+  t.apply_gradients(ids, np.array([[2.0]], np.float32), [0.1], global_step=1)
+  _, rows, _ = t.export()
+  assert abs(rows[0][0] - 0.1) < 1e-7 and rows[0][1:3].view(np.int64)[0] == 1
+  t.apply_gradients(ids, np.array([[2.0]], np.float32), [0.1])  # the test's default step 0
+  _, rows, _ = t.export()
+  assert abs(rows[0][0] - (0.9 * 0.1 + 0.1 * -1.0)) < 1e-7 and rows[0][1:3].view(np.int64)[0] == 0
+  # two occurrences without dedup = two steps at the same global_step: the second sees 0 elapsed
+  t = cpu.OracleTable([cpu.seg(1, "batch_softmax")])
+  t.apply_gradients(np.array([3, 3], np.int64), np.zeros((2, 1), np.float32), [0.5], global_step=8)
+  _, rows, _ = t.export()
+  assert rows[0][0] == 0.5 * (0.5 * 8.0)
 
 
 def test_moving_average_segment_has_no_optimizer_dump():
@@ -167,6 +185,10 @@ CASES = {
     "mixed_ma": {"segments": [{"dim": 3, "opt": "moving_average"}, {"dim": 2, "opt": "adam"},
                               {"dim": 1, "opt": "moving_average", "momentum": 0.5},
                               {"dim": 2, "opt": "adagrad"}]},
+    "batch_softmax": {"segments": [{"dim": 1, "opt": "batch_softmax"}]},
+    "mixed_bs": {"segments": [{"dim": 2, "opt": "adagrad"}, {"dim": 1, "opt": "batch_softmax"},
+                              {"dim": 2, "opt": "moving_average"}, {"dim": 1, "opt": "batch_softmax"},
+                              {"dim": 3, "opt": "adam"}]},
     "mixed": {"segments": [{"dim": 1, "opt": "ftrl", "init_acc": 0.1, "beta": 1.0},
                            {"dim": 3, "opt": "adadelta"}, {"dim": 4, "opt": "momentum"},
                            {"dim": 2, "opt": "rmsprop"}, {"dim": 6, "opt": "adagrad"},
@@ -192,7 +214,8 @@ def test_hip_matches_oracle(name, dedup):
     g = rng.normal(0, 0.3, (n, dim)).astype(np.float32)
     lrs = [0.01 * (s + 1) for s in range(n_seg)]
     for t in (o, h):
-      t.apply_gradients(ids, g, lrs, req_time=100 + step, global_step=step, enable_dedup=dedup)
+      t.apply_gradients(ids, g, lrs, req_time=100 + step, global_step=step * step * 1000003,
+                        enable_dedup=dedup)
     probe = np.arange(-60, 720, dtype=np.int64)
     assert np.array_equal(o.lookup(probe).view(np.uint32), h.lookup(probe).view(np.uint32)), step
   oi, orows, ots = o.export()
@@ -221,11 +244,15 @@ def test_new_optimizer_tables_save_and_restore(tmp_path):
                           y.view(np.uint32) if y.dtype == np.float32 else y)
   layout = ck.DumpLayout.from_table_config(hip_backend.table_config(cfg))
   assert layout.row_floats == h.row_floats == 20 + 2 + 6 + 4 + 2 + 6 + 2
-  # a segment without optimizer dump between dumping ones
-  cfg = CASES["mixed_ma"]
+  # a segment without optimizer dump between dumping ones; int64 state dumped as a varint
+  for name, dim, nseg, gstep in (("mixed_ma", 8, 4, 0), ("mixed_bs", 9, 5, 2**33 + 7)):
+    _save_restore_roundtrip(hip_backend, CASES[name], ids, rng, dim, nseg, gstep, str(tmp_path / name))
+
+
+def _save_restore_roundtrip(hip_backend, cfg, ids, rng, dim, nseg, gstep, base):
   h = hip_backend.make_table(cfg)
-  h.apply_gradients(ids, rng.normal(0, 1, (500, 8)).astype(np.float32), [0.01] * 4, req_time=78)
-  base = str(tmp_path / "ma")
+  h.apply_gradients(ids, rng.normal(0, 1, (500, dim)).astype(np.float32), [0.01] * nseg,
+                    req_time=78, global_step=gstep)
   h.t.save(base)
   h2 = hip_backend.make_table(cfg)
   h2.t = h2.t.restore(base)
