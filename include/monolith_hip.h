@@ -39,6 +39,10 @@ enum {
    * A = global_step; A is an int64 kept in the segment's two state floats (low | high word) */
   MONO_OPT_BATCH_SOFTMAX = 10
 };
+/* compressor/float_compressor.cc:42-137 (FloatCompressorConfig, float_compressor.proto:19-52) */
+enum { MONO_COMP_FP32 = 0, MONO_COMP_FP16 = 1, MONO_COMP_FIXED_R8 = 2, MONO_COMP_ONE_BIT = 3 };
+/* EntryConfig.EntryType (embedding_hash_table.proto:35-42) */
+enum { MONO_ENTRY_TRAINING = 1, MONO_ENTRY_SERVING = 2 };
 enum { MONO_INIT_ZEROS = 0, MONO_INIT_ONES = 1, MONO_INIT_CONSTANT = 2, MONO_INIT_UNIFORM = 3 };
 
 typedef struct {
@@ -62,6 +66,10 @@ typedef struct {
   /* ABI version 3: */
   float beta1;           /* Adam / AMSGrad (0.9) */
   float beta2;           /* Adam / AMSGrad (0.99) */
+  /* ABI version 4 (serving entries only, entry_type MONO_ENTRY_SERVING): */
+  int32_t comp_kind;     /* MONO_COMP_* */
+  float comp_a;          /* FixedR8: r (1.0); OneBit: amplitude (0.1) */
+  float comp_b;          /* OneBit: init_scale (1.0) */
 } mono_segment_cfg;
 
 typedef struct {
@@ -70,7 +78,9 @@ typedef struct {
   const mono_segment_cfg* segments;  /* host pointer, n_segments entries */
   int64_t initial_capacity;          /* rows the table must hold before its first rehash */
   int32_t n_slot_expire;             /* SlotExpireTimeConfig.slot_expire_times */
-  int32_t reserved;
+  int32_t entry_type;                /* 0 / MONO_ENTRY_TRAINING, or MONO_ENTRY_SERVING: values are
+                                        stored as the segment's compressor would return them
+                                        (entry_accessor.cc:43-98); no optimizer, no save */
   const int32_t* slot_ids;           /* host pointer */
   const int32_t* slot_expire_days;   /* host pointer */
   uint64_t seed;                     /* seed of the random_uniform initializer */

@@ -22,13 +22,14 @@ class SegCfg(C.Structure):  # mono_segment_cfg
               ("beta", C.c_float), ("init_kind", C.c_int32), ("init_a", C.c_float),
               ("init_b", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float),
               ("averaging_ratio", C.c_float), ("learning_rate", C.c_float),
-              ("use_nesterov", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float)]
+              ("use_nesterov", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float),
+              ("comp_kind", C.c_int32), ("comp_a", C.c_float), ("comp_b", C.c_float)]
 
 
 class TableCfg(C.Structure):  # mono_table_cfg
   _fields_ = [("n_segments", C.c_int32), ("default_expire_days", C.c_int32),
               ("segments", C.POINTER(SegCfg)), ("initial_capacity", C.c_int64),
-              ("n_slot_expire", C.c_int32), ("reserved", C.c_int32),
+              ("n_slot_expire", C.c_int32), ("entry_type", C.c_int32),
               ("slot_ids", C.POINTER(C.c_int32)), ("slot_expire_days", C.POINTER(C.c_int32)),
               ("seed", C.c_uint64)]
 

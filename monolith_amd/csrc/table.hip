@@ -47,6 +47,8 @@ struct SegDev {
   float momentum, epsilon, rho, conf_lr;
   int nesterov;
   float beta1, beta2;
+  int comp_kind;    // serving tables: MONO_COMP_*
+  float cq0, cq1;   // FixedR8: step, half step; OneBit: amplitude, scale
 };
 
 // per-element optimizer state slots of a row: norm | (FTRL) zero; n; accum | accum_update;
@@ -78,6 +80,7 @@ struct TableDev {  // passed to kernels by value
   uint64_t bucket_mask;
   int dim, row_floats, n_seg;
   int default_expire_days;
+  int serving;  // MONO_ENTRY_SERVING: writes store compressor round trips (comp_q)
   uint64_t seed;
   const int32_t* slot_expire;  // int32[32768] or nullptr
   SegDev seg[kMaxSeg];
@@ -504,6 +507,27 @@ __device__ inline int64_t segment_end(const K* keys, int64_t j, int64_t n, K key
 
 // One optimizer step on one element. Non-contracted arithmetic
 // (-ffp-contract=off) with correctly rounded sqrt/div, i.e. the reference's baseline form.
+// Serving entries (entry_accessor.cc:43-98) keep what the segment's compressor returns for a
+// value: Decode(Encode(v)) of float_compressor.cc:63-137, stored as fp32 (the rows are not
+// narrowed; a table too large for that is a training table restored shard by shard).
+__device__ __forceinline__ float comp_q(const SegDev& c, float v) {
+  if (c.comp_kind == MONO_COMP_FP16) {  // half_float::half(v): to nearest, ties to even
+    return __half2float(__float2half_rn(v));
+  } else if (c.comp_kind == MONO_COMP_FIXED_R8) {  // fake_quantizer.h:35-60
+    if (isnan(v)) return 0.f * c.cq0;
+    const float f = v >= 0 ? v + c.cq1 : v - c.cq1;
+    const float q = __fdiv_rn(f, c.cq0);
+    // int nstep = f / step_: out of int range the reference's x86 conversion yields INT_MIN
+    int nstep = (fabsf(q) < 2147483648.f) ? (int)q : (int)0x80000000;
+    nstep = nstep > 127 ? 127 : (nstep < -128 ? -128 : nstep);
+    return (float)nstep * c.cq0;
+  } else if (c.comp_kind == MONO_COMP_ONE_BIT) {  // hash_net_quantizer.h:42-44, :120-131
+    const float y = c.cq0 * tanhf(c.cq1 * v);
+    return (y > 0 ? 1.f : -1.f) * c.cq0;
+  }
+  return v;
+}
+
 // third state slot + per-row scalars (generic path only; the specialised kernels pass a dummy)
 struct OptX {
   float s2 = 0.f, b1p = 0.f, b2p = 0.f;
@@ -722,7 +746,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
     }
   }
 
-  if (end - first > kLongSeg && D <= kLongMaxDim &&
+  if (end - first > kLongSeg && D <= kLongMaxDim && !t.serving &&
       (a.mode == MODE_ASSIGN_ADD || a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP)) {
     if (sub == 0) enqueue_long(a, first, end, key, slot, fresh ? 1u : 0u);
     return;
@@ -731,7 +755,16 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
   float* row = t.rows + (uint64_t)slot * R;
   if (a.mode == MODE_IMPORT) {  // full-row restore: last occurrence wins
     uint32_t src_i = a.sidx[end - 1];
-    for (int e = sub; e < R; e += 8) row[e] = a.src[(uint64_t)src_i * R + e];
+    if (t.serving) {  // Restore = Encode(dump.num) (entry_accessor.cc:89-94); R == D here
+      for (int e = sub; e < R; e += 8) {
+        int sgi = 0;
+        for (int z = 0; z < t.n_seg; ++z)
+          if (e >= t.seg[z].w_off) sgi = z;
+        row[e] = comp_q(t.seg[sgi], a.src[(uint64_t)src_i * R + e]);
+      }
+    } else {
+      for (int e = sub; e < R; e += 8) row[e] = a.src[(uint64_t)src_i * R + e];
+    }
     if (sub == 0) t.ts[slot] = a.src_ts[src_i];
     return;
   }
@@ -793,12 +826,20 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
     // --- walk the occurrences in input order
     if (a.mode == MODE_ASSIGN) {
       vload<V>(w, a.src + (uint64_t)a.sidx[end - 1] * D + e0);
+      if (OPTK == OPTK_MULTI && t.serving) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) w[q] = comp_q(t.seg[segi[q]], w[q]);
+      }
     } else if (a.mode == MODE_ASSIGN_ADD) {
       for (int64_t p = first; p < end; ++p) {
         float g[V];
         vload<V>(g, a.src + (uint64_t)a.sidx[p] * D + e0);
 #pragma unroll
         for (int q = 0; q < V; ++q) w[q] += g[q];
+        if (OPTK == OPTK_MULTI && t.serving) {  // every AssignAdd re-encodes (entry_accessor.cc:70-77)
+#pragma unroll
+          for (int q = 0; q < V; ++q) w[q] = comp_q(t.seg[segi[q]], w[q]);
+        }
       }
     } else if (a.mode == MODE_OPT_SEQ) {
       for (int64_t p = first; p < end; ++p) {
@@ -1432,7 +1473,8 @@ static void launch_short(const Table* t, const ApplyArgs& a, hipStream_t st) {
 static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, hipStream_t st) {
   const bool walks =
       a.mode == MODE_ASSIGN_ADD || a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP;
-  const bool allow_long = walks && a.n > kLongSeg && t->d.dim <= kLongMaxDim;
+  // (a serving entry re-encodes after every add: its segments are walked whole, never chunked)
+  const bool allow_long = walks && a.n > kLongSeg && t->d.dim <= kLongMaxDim && !t->d.serving;
   const unsigned lgrid = (unsigned)std::min<int64_t>(a.n / kLongSeg + 1, 1024);
   if (a.from_keys) {
     // filter path: the sub-group kernel resolves / gates / claims and feeds the long queue
@@ -1654,10 +1696,21 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
     MONO_REQUIRE(total_dim <= kTileFloats, "mono_table_create: dim %lld exceeds %d",
                  (long long)total_dim, kTileFloats);
   }
+  const bool serving = cfg->entry_type == MONO_ENTRY_SERVING;
+  MONO_REQUIRE(cfg->entry_type == 0 || cfg->entry_type == MONO_ENTRY_TRAINING || serving,
+               "mono_table_create: unknown entry type %d", cfg->entry_type);
   Table* t = new Table();
   int w = 0;
   for (int s = 0; s < cfg->n_segments; ++s) {
-    const mono_segment_cfg& c = cfg->segments[s];
+    mono_segment_cfg c = cfg->segments[s];
+    if (serving) {  // entry_accessor.cc:315-318: a serving entry is its compressor, nothing else
+      c.opt_kind = MONO_OPT_SGD;
+      c.init_kind = MONO_INIT_ZEROS;
+      if (c.comp_kind < MONO_COMP_FP32 || c.comp_kind > MONO_COMP_ONE_BIT) {
+        delete t;
+        return fail("Unknown tpye of float compressor. %d", c.comp_kind);  // float_compressor.cc:195
+      }
+    }
     if (c.dim <= 0 || c.opt_kind < 0 || c.opt_kind > MONO_OPT_BATCH_SOFTMAX || c.init_kind < 0 ||
         c.init_kind > MONO_INIT_UNIFORM ||
         (c.opt_kind == MONO_OPT_BATCH_SOFTMAX && c.dim != 1)) {  // DCHECK_EQ(dim_size, 1)
@@ -1672,8 +1725,9 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
   d.dim = w;
   d.n_seg = cfg->n_segments;
   int st = w, wo = 0;
+  d.serving = serving ? 1 : 0;
   for (int s = 0; s < cfg->n_segments; ++s) {
-    const mono_segment_cfg& c = cfg->segments[s];
+    const mono_segment_cfg& c = t->segs[s];
     SegDev& sd = d.seg[s];
     sd.dim = c.dim; sd.opt_kind = c.opt_kind; sd.w_off = wo; sd.st_off = st;
     sd.init_kind = c.init_kind; sd.init_acc = c.init_acc; sd.wd = c.weight_decay;
@@ -1681,6 +1735,15 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
     sd.momentum = c.momentum; sd.epsilon = c.epsilon; sd.rho = c.averaging_ratio;
     sd.conf_lr = c.learning_rate; sd.nesterov = c.use_nesterov;
     sd.beta1 = c.beta1; sd.beta2 = c.beta2;
+    sd.comp_kind = serving ? c.comp_kind : MONO_COMP_FP32;
+    sd.cq0 = sd.cq1 = 0.f;
+    if (sd.comp_kind == MONO_COMP_FIXED_R8) {  // fake_quantizer.h:28-29: step = r / 128, half step
+      sd.cq0 = c.comp_a / 128;
+      sd.cq1 = sd.cq0 / 2;
+    } else if (sd.comp_kind == MONO_COMP_ONE_BIT) {
+      sd.cq0 = c.comp_a;
+      sd.cq1 = c.comp_b;
+    }
     wo += c.dim;
     st += opt_state_floats(c.opt_kind, c.dim);
   }
@@ -1689,7 +1752,7 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
   d.default_expire_days = cfg->default_expire_days;
   // the three reference-config optimizers have specialised kernels; the rest (and mixes) take
   // the generic per-element path
-  t->opt_tmpl = cfg->n_segments == 1 && cfg->segments[0].opt_kind <= MONO_OPT_FTRL
+  t->opt_tmpl = !serving && cfg->n_segments == 1 && cfg->segments[0].opt_kind <= MONO_OPT_FTRL
                     ? cfg->segments[0].opt_kind : OPTK_MULTI;
   // floats per lane: the widest access that still keeps all 8 lanes of a sub-group busy
   t->vec = 1;
@@ -1819,6 +1882,7 @@ int mono_table_apply_gradients(void* table, void* filter, const int64_t* ids, co
                                void* stream) {
   MONO_REQUIRE(table, "mono_table_apply_gradients: null table");
   Table* t = (Table*)table;
+  MONO_REQUIRE(!t->d.serving, "ServingEntryAccessor doesn't support Optimize");  // entry_accessor.cc:79-83
   for (int s = 0; s < t->d.n_seg; ++s)  // batch_softmax_optimizer.cc:49-52 (LOG(FATAL) there)
     MONO_REQUIRE(t->d.seg[s].opt_kind != MONO_OPT_BATCH_SOFTMAX || global_step >= 0,
                  "global_step=%lld is negative, please investigate!", (long long)global_step);

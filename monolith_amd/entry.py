@@ -168,7 +168,30 @@ class RandomUniformInitializer(Initializer):  # entry.py:403-418
 
 @dataclasses.dataclass
 class Fp32Compressor:  # entry.py:482-488 (training entries ignore the compressor)
-  pass
+  kind = 0
+
+
+@dataclasses.dataclass
+class Fp16Compressor:  # entry.py:472-479, float_compressor.proto:27-29
+  kind = 1
+
+
+@dataclasses.dataclass
+class FixedR8Compressor:  # entry.py:459-469, float_compressor.proto:31-34
+  fixed_range: float = 1.0
+  kind = 2
+
+  @property
+  def r(self):
+    return self.fixed_range
+
+
+@dataclasses.dataclass
+class OneBitCompressor:  # entry.py:444-456, float_compressor.proto:37-43
+  step_size: int = 200
+  amplitude: float = 0.05
+  init_scale: float = 1.0
+  kind = 3
 
 
 @dataclasses.dataclass
@@ -205,6 +228,10 @@ class EmbeddingHashTableConfig:  # embedding_hash_table.proto:67-87
   enable_feature_eviction: bool = False
   feature_evict_every_n_hours: int = 240
   seed: int = 0  # build-defined: seed of the counter-based random_uniform initializer
+  # EntryConfig.entry_type (embedding_hash_table.proto:35-42): "serving" = values stored as the
+  # segments' compressors return them, lookup / assign / assign_add / restore only
+  # (hash_table_ops.py:465-466 switches to it when exporting)
+  entry_type: str = "training"
 
   @property
   def dim_size(self):  # hash_table_utils.py:45-50 (infer_dim_size)

@@ -10,6 +10,7 @@ import os
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from monolith_amd import _lib
@@ -105,6 +106,12 @@ class _TableResource:
       seg.use_nesterov = int(bool(getattr(o, "use_nesterov", False)))
       seg.beta1 = getattr(o, "beta1", 0.9)
       seg.beta2 = getattr(o, "beta2", 0.99)
+      comp = s.comp_config
+      seg.comp_kind = getattr(comp, "kind", 0) or 0
+      if isinstance(comp, entry.FixedR8Compressor):
+        seg.comp_a = comp.fixed_range
+      elif isinstance(comp, entry.OneBitCompressor):
+        seg.comp_a, seg.comp_b = comp.amplitude, comp.init_scale
       if isinstance(i, entry.ConstantsInitializer):
         seg.init_a = i.constant
       elif isinstance(i, entry.RandomUniformInitializer):
@@ -117,7 +124,9 @@ class _TableResource:
     sl = (C.c_int32 * max(n, 1))(*list(se.keys()))
     dd = (C.c_int32 * max(n, 1))(*list(se.values()))
     cfg = _lib.TableCfg(len(segs), table_config.slot_expire_time_config.default_expire_time, arr,
-                        table_config.initial_capacity, n, 0, sl, dd, table_config.seed)
+                        table_config.initial_capacity, n,
+                        2 if table_config.entry_type == "serving" else 0, sl, dd, table_config.seed)
+    self.serving = table_config.entry_type == "serving"
     self.h = C.c_void_p()
     self.filter = hash_filter
     self.config = table_config
@@ -331,6 +340,8 @@ def _save_restore_methods():
   from monolith_amd import checkpoint
 
   def save(self, basename: str, random_sleep_ms: int = 0) -> "HashTable":
+    if self._table.serving:  # entry_accessor.cc:85-87
+      raise RuntimeError("ServingEntryAccessor doesn't support Save")
     # save-time expiry: rows older than their slot's expire time are skipped (:142-150)
     ids, rows, ts = self.save_as_tensor(apply_expiry=True)
     layout = checkpoint.DumpLayout.from_table_config(self._table.config)
@@ -342,6 +353,8 @@ def _save_restore_methods():
   def restore(self, basename: str) -> "HashTable":
     layout = checkpoint.DumpLayout.from_table_config(self._table.config)
     ids, rows, ts = checkpoint.read_shards(str(basename), layout)
+    if self._table.serving:  # Restore = Encode(dump.num): the optimizer part of the dump is unused
+      rows = np.ascontiguousarray(rows[:, :self._table.dim])
     return self.restore_from_tensor(torch.from_numpy(ids), torch.from_numpy(rows),
                                     torch.from_numpy(ts.astype("int64")))
 

@@ -26,13 +26,14 @@ class SegCfg(C.Structure):
               ("beta", C.c_float), ("init_kind", C.c_int32), ("init_a", C.c_float),
               ("init_b", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float),
               ("averaging_ratio", C.c_float), ("learning_rate", C.c_float),
-              ("use_nesterov", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float)]
+              ("use_nesterov", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float),
+              ("comp_kind", C.c_int32), ("comp_a", C.c_float), ("comp_b", C.c_float)]
 
 
 class TableCfg(C.Structure):
   _fields_ = [("n_segments", C.c_int32), ("default_expire_days", C.c_int32),
               ("segments", C.POINTER(SegCfg)), ("initial_capacity", C.c_int64),
-              ("n_slot_expire", C.c_int32), ("reserved", C.c_int32),
+              ("n_slot_expire", C.c_int32), ("entry_type", C.c_int32),
               ("slot_ids", C.POINTER(C.c_int32)), ("slot_expire_days", C.POINTER(C.c_int32)),
               ("seed", C.c_uint64)]
 
@@ -80,7 +81,8 @@ def _ptr_array(arrs):
 
 def seg(dim, opt="sgd", init="zeros", init_acc=0.1, weight_decay=0.0, l1=0.0, l2=0.0, beta=0.0,
         init_a=0.0, init_b=0.0, momentum=0.9, epsilon=0.01, averaging_ratio=0.9,
-        learning_rate=0.01, use_nesterov=False, beta1=0.9, beta2=0.99):
+        learning_rate=0.01, use_nesterov=False, beta1=0.9, beta2=0.99, comp="fp32", comp_a=0.0,
+        comp_b=1.0):
   ok = {"sgd": OPT_SGD, "adagrad": OPT_ADAGRAD, "ftrl": OPT_FTRL, "momentum": OPT_MOMENTUM,
         "rmsprop": OPT_RMSPROP, "rmspropv2": OPT_RMSPROP_V2, "adadelta": OPT_ADADELTA,
         "adam": OPT_ADAM, "amsgrad": OPT_AMSGRAD, "moving_average": OPT_MOVING_AVERAGE,
@@ -88,18 +90,20 @@ def seg(dim, opt="sgd", init="zeros", init_acc=0.1, weight_decay=0.0, l1=0.0, l2
   ik = {"zeros": INIT_ZEROS, "ones": INIT_ONES, "constant": INIT_CONSTANT,
         "uniform": INIT_UNIFORM}[init]
   return SegCfg(dim, ok, init_acc, weight_decay, l1, l2, beta, ik, init_a, init_b, momentum,
-                epsilon, averaging_ratio, learning_rate, int(bool(use_nesterov)), beta1, beta2)
+                epsilon, averaging_ratio, learning_rate, int(bool(use_nesterov)), beta1, beta2,
+                {"fp32": 0, "fp16": 1, "fixed_r8": 2, "one_bit": 3}[comp], comp_a, comp_b)
 
 
 def make_table_cfg(segments, initial_capacity=1, default_expire_days=36500, slot_expire=None,
-                   seed=0):
+                   seed=0, serving=False):
   """Returns (TableCfg, keepalive)."""
   segs = (SegCfg * len(segments))(*segments)
   slot_expire = slot_expire or {}
   n = len(slot_expire)
   sl = (C.c_int32 * max(n, 1))(*list(slot_expire.keys()))
   dd = (C.c_int32 * max(n, 1))(*list(slot_expire.values()))
-  cfg = TableCfg(len(segments), default_expire_days, segs, initial_capacity, n, 0, sl, dd, seed)
+  cfg = TableCfg(len(segments), default_expire_days, segs, initial_capacity, n,
+                 2 if serving else 0, sl, dd, seed)
   return cfg, (segs, sl, dd)
 
 
@@ -154,8 +158,9 @@ class OracleFilter:
 class OracleTable:
 
   def __init__(self, segments, initial_capacity=1, default_expire_days=36500, slot_expire=None,
-               seed=0):
-    cfg, keep = make_table_cfg(segments, initial_capacity, default_expire_days, slot_expire, seed)
+               seed=0, serving=False):
+    cfg, keep = make_table_cfg(segments, initial_capacity, default_expire_days, slot_expire, seed,
+                               serving)
     self.h = C.c_void_p(lib().orc_table_create(C.byref(cfg)))
     self.dim = lib().orc_table_dim(self.h)
     self.row_floats = lib().orc_table_row_floats(self.h)

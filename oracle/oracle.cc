@@ -25,6 +25,7 @@
 #include <memory>
 #include <thread>
 #include <unordered_map>
+#include <limits>
 #include <vector>
 
 namespace {
@@ -32,6 +33,8 @@ namespace {
 enum { OPT_SGD = 0, OPT_ADAGRAD = 1, OPT_FTRL = 2, OPT_MOMENTUM = 3, OPT_RMSPROP = 4,
        OPT_RMSPROP_V2 = 5, OPT_ADADELTA = 6, OPT_ADAM = 7, OPT_AMSGRAD = 8,
        OPT_MOVING_AVERAGE = 9, OPT_BATCH_SOFTMAX = 10 };
+enum { COMP_FP32 = 0, COMP_FP16 = 1, COMP_FIXED_R8 = 2, COMP_ONE_BIT = 3 };
+enum { ENTRY_TRAINING = 1, ENTRY_SERVING = 2 };
 enum { INIT_ZEROS = 0, INIT_ONES = 1, INIT_CONSTANT = 2, INIT_UNIFORM = 3 };
 
 struct SegCfg {  // == mono_segment_cfg
@@ -45,6 +48,8 @@ struct SegCfg {  // == mono_segment_cfg
   float momentum, epsilon, averaging_ratio, learning_rate;
   int32_t use_nesterov;
   float beta1, beta2;
+  int32_t comp_kind;  // serving entries: COMP_*
+  float comp_a, comp_b;
 };
 
 // floats of optimizer context: SizeBytes() / sizeof(float) of the reference optimizers
@@ -65,7 +70,7 @@ struct TableCfg {  // == mono_table_cfg
   const SegCfg* segments;
   int64_t initial_capacity;
   int32_t n_slot_expire;
-  int32_t reserved;
+  int32_t entry_type;
   const int32_t* slot_ids;
   const int32_t* slot_expire_days;
   uint64_t seed;
@@ -235,6 +240,59 @@ struct Filter {
   }
 };
 
+// ---------------------------------------------------------------- serving compressors
+// float -> IEEE binary16 (to nearest, ties to even: what half_float::half(float) of the
+// reference's third_party/half_sourceforge_net/half.hpp does with its default HALF_ROUND_STYLE 1;
+// checked against that header in tests/test_serving.py) -> float.
+inline float fp16_roundtrip(float v) {
+  uint32_t x;
+  std::memcpy(&x, &v, 4);
+  const uint32_t sign = x & 0x80000000u;
+  const uint32_t ax = x & 0x7FFFFFFFu;
+  uint32_t out;
+  if (ax >= 0x7F800000u) {                       // inf / nan
+    out = ax > 0x7F800000u ? (ax | 0x00400000u) : ax;
+  } else if (ax >= 0x477FF000u) {                // >= 65520: rounds to infinity
+    out = 0x7F800000u;
+  } else if (ax >= 0x38800000u) {                // normal half: keep 10 mantissa bits
+    const uint32_t rem = ax & 0x1FFFu, base = ax & ~0x1FFFu;
+    out = base + ((rem > 0x1000u || (rem == 0x1000u && (base & 0x2000u))) ? 0x2000u : 0u);
+  } else {                                       // half subnormal: multiples of 2^-24
+    float a;
+    std::memcpy(&a, &ax, 4);
+    const float scaled = a * 16777216.0f;        // exact: a < 2^-14
+    float r = std::nearbyint(scaled);            // default mode: ties to even
+    a = r * (1.0f / 16777216.0f);
+    std::memcpy(&out, &a, 4);
+  }
+  out |= sign;
+  float res;
+  std::memcpy(&res, &out, 4);
+  return res;
+}
+
+// Decode(Encode(v)) of float_compressor.cc:63-137 for one value
+inline float comp_q(const SegCfg& c, float v) {
+  if (c.comp_kind == COMP_FP16) return fp16_roundtrip(v);
+  if (c.comp_kind == COMP_FIXED_R8) {  // fake_quantizer.h:28-64
+    const float step = c.comp_a / 128, half_step = step / 2;
+    if (std::isnan(v)) return 0 * step;
+    float f = v;
+    if (f >= 0) f += half_step; else f -= half_step;
+    const float q = f / step;
+    // `int nstep = f / step_`: beyond the int range the x86 conversion the reference is built
+    // for returns INT_MIN (the "integer indefinite"); stated explicitly instead of relying on it
+    int nstep = (std::fabs(q) < 2147483648.f) ? (int)q : std::numeric_limits<int>::min();
+    if (nstep > 127) nstep = 127; else if (nstep < -128) nstep = -128;
+    return (int8_t)nstep * step;
+  }
+  if (c.comp_kind == COMP_ONE_BIT) {  // hash_net_quantizer.h:42-44 with scale = init_scale
+    const float y = c.comp_a * std::tanh(c.comp_b * v);
+    return static_cast<float>(y > 0 ? 1 : -1) * c.comp_a;
+  }
+  return v;
+}
+
 // ---------------------------------------------------------------- table
 struct Entry {
   std::vector<float> row;  // float[dim] | opt ctx per segment (entry_accessor.cc:101-103)
@@ -248,8 +306,16 @@ struct Table {
   int default_expire_days = 36500;
   std::unordered_map<int, int> slot_expire;
   uint64_t seed = 0;
+  bool serving = false;  // entry_accessor.cc:43-98: values pass through the compressor on write
   int64_t max_update_ts = 0;
   std::unordered_map<int64_t, Entry> m;
+
+  void compress(Entry& e) const {
+    if (!serving) return;
+    for (size_t s = 0; s < segs.size(); ++s)
+      for (int i = 0; i < segs[s].dim; ++i)
+        e.row[seg_w_off[s] + i] = comp_q(segs[s], e.row[seg_w_off[s] + i]);
+  }
 
   // entry_accessor.cc:139-143 (Init = initializer then optimizer Init)
   void init_entry(int64_t id, Entry* e) const {
@@ -497,8 +563,13 @@ void orc_filter_state(void* fp, int64_t* out, int64_t out_len) {
 void* orc_table_create(const TableCfg* cfg) {
   Table* t = new Table();
   int w = 0;
+  t->serving = cfg->entry_type == ENTRY_SERVING;
   for (int s = 0; s < cfg->n_segments; ++s) {
     t->segs.push_back(cfg->segments[s]);
+    if (t->serving) {  // a serving entry is its compressor only (entry_accessor.cc:315-318)
+      t->segs.back().opt_kind = OPT_SGD;
+      t->segs.back().init_kind = INIT_ZEROS;
+    }
     t->seg_w_off.push_back(w);
     w += cfg->segments[s].dim;
   }
@@ -506,7 +577,7 @@ void* orc_table_create(const TableCfg* cfg) {
   int st = w;
   for (int s = 0; s < cfg->n_segments; ++s) {
     t->seg_st_off.push_back(st);
-    const SegCfg& c = cfg->segments[s];
+    const SegCfg& c = t->segs[s];
     st += state_floats(c.opt_kind, c.dim);
   }
   t->row_floats = st;
@@ -517,6 +588,14 @@ void* orc_table_create(const TableCfg* cfg) {
   return t;
 }
 void orc_table_destroy(void* t) { delete (Table*)t; }
+// Decode(Encode(v)) of one compressor over an array (tests compare it with the reference headers)
+void orc_compress_roundtrip(int kind, float a, float b, const float* in, float* out, int64_t n) {
+  SegCfg c{};
+  c.comp_kind = kind;
+  c.comp_a = a;
+  c.comp_b = b;
+  for (int64_t i = 0; i < n; ++i) out[i] = comp_q(c, in[i]);
+}
 int orc_table_dim(void* t) { return ((Table*)t)->dim; }
 int orc_table_row_floats(void* t) { return ((Table*)t)->row_floats; }
 
@@ -547,6 +626,7 @@ void orc_table_assign(void* tp, void* fp, const int64_t* ids, const float* value
     Entry& e = t->upsert(ids[i]);
     e.ts = (uint32_t)req_time;
     std::memcpy(e.row.data(), values + i * t->dim, sizeof(float) * t->dim);
+    t->compress(e);
   }
 }
 
@@ -561,6 +641,7 @@ void orc_table_assign_add(void* tp, void* fp, const int64_t* ids, const float* v
     Entry& e = t->upsert(ids[i]);  // cuckoo_embedding_hash_table.cc:189-195
     e.ts = (uint32_t)req_time;
     for (int j = 0; j < t->dim; ++j) e.row[j] += values[i * t->dim + j];
+    t->compress(e);
   }
 }
 
@@ -661,6 +742,7 @@ void orc_table_import(void* tp, const int64_t* ids, const float* rows, const uin
   for (int64_t i = 0; i < n; ++i) {
     Entry& e = t->upsert(ids[i]);
     std::memcpy(e.row.data(), rows + i * t->row_floats, sizeof(float) * t->row_floats);
+    t->compress(e);
     e.ts = ts[i];
     t->max_update_ts = std::max<int64_t>(t->max_update_ts, ts[i]);
   }

@@ -53,10 +53,23 @@ def _init(d):
   return entry.RandomUniformInitializer(d.get("init_a", -0.05), d.get("init_b", 0.05))
 
 
+def _comp(d):
+  k = d.get("comp", "fp32")
+  if k == "fp16":
+    return entry.Fp16Compressor()
+  if k == "fixed_r8":
+    return entry.FixedR8Compressor(d.get("comp_a", 1.0))
+  if k == "one_bit":
+    return entry.OneBitCompressor(amplitude=d.get("comp_a", 0.05), init_scale=d.get("comp_b", 1.0))
+  return entry.Fp32Compressor()
+
+
 def table_config(cfg):
   tc = entry.EmbeddingHashTableConfig(
-      segments=[entry.CombineAsSegment(s["dim"], _init(s), _opt(s)) for s in cfg["segments"]],
-      initial_capacity=cfg.get("initial_capacity", 1), seed=cfg.get("seed", 0))
+      segments=[entry.CombineAsSegment(s["dim"], _init(s), _opt(s), _comp(s))
+                for s in cfg["segments"]],
+      initial_capacity=cfg.get("initial_capacity", 1), seed=cfg.get("seed", 0),
+      entry_type="serving" if cfg.get("serving") else "training")
   tc.slot_expire_time_config.default_expire_time = cfg.get("default_expire_days", 36500)
   tc.slot_expire_time_config.slot_expire_times = {
       int(k): v for k, v in cfg.get("slot_expire", {}).items()}

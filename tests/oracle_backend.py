@@ -11,7 +11,8 @@ def seg_from_dict(d):
                  averaging_ratio=d.get("averaging_ratio", 0.9),
                  learning_rate=d.get("learning_rate", 0.01),
                  use_nesterov=d.get("use_nesterov", False), beta1=d.get("beta1", 0.9),
-                 beta2=d.get("beta2", 0.99))
+                 beta2=d.get("beta2", 0.99), comp=d.get("comp", "fp32"),
+                 comp_a=d.get("comp_a", 0.0), comp_b=d.get("comp_b", 1.0))
 
 
 def make_table(cfg):
@@ -19,7 +20,7 @@ def make_table(cfg):
                          initial_capacity=cfg.get("initial_capacity", 1),
                          default_expire_days=cfg.get("default_expire_days", 36500),
                          slot_expire={int(k): v for k, v in cfg.get("slot_expire", {}).items()},
-                         seed=cfg.get("seed", 0))
+                         seed=cfg.get("seed", 0), serving=bool(cfg.get("serving")))
 
 
 def make_filter(cfg):
