@@ -231,6 +231,18 @@ __global__ void __launch_bounds__(256) k_gather_rows(const float* __restrict__ f
   }
 }
 
+// ... four floats per thread: every dim of the call is a multiple of 4 (so every offset is) and
+// the buffers are 16-byte aligned. 32-bit index arithmetic (the host checks the range).
+__global__ void __launch_bounds__(256) k_gather_rows4(const float4* __restrict__ fused,
+                                                      const int32_t* __restrict__ off, uint32_t len,
+                                                      uint32_t quads, float4* __restrict__ out) {
+  const uint32_t total = len * quads;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const uint32_t j = e / quads, k = e - j * quads;
+    out[e] = fused[((uint32_t)off[j] >> 2) + k];
+  }
+}
+
 // ------------------------------------------------------------------------------ F1 reorder
 struct ReorderArgs {
   int M, N, shard_rule;
@@ -607,10 +619,19 @@ int mono_fused_gather_embeddings_by_input(const float* fused, int64_t fused_len,
                                           void* stream) {
   (void)fused_len;
   hipStream_t st = (hipStream_t)stream;
+  bool quads = ((uintptr_t)fused & 15) == 0;
+  for (int m = 0; m < M; ++m)
+    quads = quads && h_dims[m] % 4 == 0 && ((uintptr_t)outs[m] & 15) == 0 &&
+            h_lens[m] * h_dims[m] < (int64_t)0x7FFFFFF0;
   for (int m = 0; m < M; ++m) {
     if (h_lens[m] == 0) continue;
-    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(h_lens[m] * h_dims[m], 256)), dim3(256), 0, st,
-                       fused, offsets[m], h_lens[m], h_dims[m], outs[m]);
+    if (quads)
+      hipLaunchKernelGGL(k_gather_rows4, dim3(grid_for(h_lens[m] * (h_dims[m] / 4), 256)), dim3(256),
+                         0, st, (const float4*)fused, offsets[m], (uint32_t)h_lens[m],
+                         (uint32_t)(h_dims[m] / 4), (float4*)outs[m]);
+    else
+      hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(h_lens[m] * h_dims[m], 256)), dim3(256), 0, st,
+                         fused, offsets[m], h_lens[m], h_dims[m], outs[m]);
   }
   MONO_HIP(hipGetLastError());
   return 0;

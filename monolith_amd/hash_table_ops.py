@@ -424,8 +424,12 @@ def fused_lookup(tables: List, ids, fused_slot_size, num_of_shards: int):
   args = (hs, C.c_int(K), _lib.vp(ids), C.c_void_p(fss.data_ptr()), C.c_int(N))
   meta = (C.c_void_p(splits.data_ptr()), C.c_void_p(id_off.data_ptr()),
           C.c_void_p(emb_off.data_ptr()), C.c_void_p(emb_sizes.data_ptr()))
-  _lib.check(_lib.lib.mono_tables_fused_lookup(*args, None, *meta, _lib.stream_ptr()))
-  emb = torch.empty(int(splits.sum()), dtype=torch.float32, device=ids.device)
+  # output length = sum over (shard, table) cells of ids * dim: known on the host, so the kernels
+  # go out with ONE call (the caller is often waiting on a size it just read back: the time to
+  # the first launch is GPU idle time)
+  dims = [r.dim for r in res]
+  total = sum(int(c) * dims[i % K] for i, c in enumerate(fss.tolist()))
+  emb = torch.empty(total, dtype=torch.float32, device=ids.device)
   _lib.check(_lib.lib.mono_tables_fused_lookup(*args, _lib.vp(emb), *meta, _lib.stream_ptr()))
   return emb, splits, id_off, emb_off, emb_sizes
 

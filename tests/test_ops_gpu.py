@@ -98,6 +98,24 @@ def test_fused_gather_and_gradient(ops):
   eg = cpu.fused_gather_embeddings_by_input_gradient(fused_len, grads, offs, dims)
   assert np.array_equal(bits(ft.grad), bits(eg))
 
+  # every dim a multiple of 4: the four-floats-per-thread gather; then the same through a fused
+  # buffer that is not 16-byte aligned (scalar kernel again)
+  dims, rows = [8, 4, 16], [300, 50, 2000]
+  base, fused_len = [], 0
+  for r, d in zip(rows, dims):
+    base.append(fused_len)
+    fused_len += r * d
+  fused = rng.normal(0, 1, fused_len + 1).astype(np.float32)
+  offs = [(b + rng.integers(0, r, n) * d).astype(np.int32)
+          for b, r, d, n in zip(base, rows, dims, [5000, 7, 30001])]
+  whole = T(fused, torch.float32)
+  for shift in (0, 1):
+    view = whole[shift:shift + fused_len]
+    outs = d_ops.fused_gather_embeddings_by_input(view, [T(o, torch.int32) for o in offs], dims)
+    exp = cpu.fused_gather_embeddings_by_input(fused[shift:shift + fused_len], offs, dims)
+    for a, b in zip(outs, exp):
+      assert np.array_equal(bits(a), bits(b)), shift
+
 
 # ----------------------------------------------------------------------------- pooling
 def test_combiners_reference_vectors(ops):
