@@ -70,6 +70,10 @@ typedef struct {
   int32_t comp_kind;     /* MONO_COMP_* */
   float comp_a;          /* FixedR8: r (1.0); OneBit: amplitude (0.1) */
   float comp_b;          /* OneBit: init_scale (1.0) */
+  int32_t stochastic_rounding_float16; /* OptimizerConfig.stochastic_rounding_float16
+                            (optimizer.proto:213, stochastic_rounding.h:27-56): after the segment's
+                            step every weight from the segment's first to the END of the entry is
+                            rounded to one of its two binary16 neighbours */
 } mono_segment_cfg;
 
 typedef struct {

@@ -23,7 +23,8 @@ class SegCfg(C.Structure):  # mono_segment_cfg
               ("init_b", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float),
               ("averaging_ratio", C.c_float), ("learning_rate", C.c_float),
               ("use_nesterov", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float),
-              ("comp_kind", C.c_int32), ("comp_a", C.c_float), ("comp_b", C.c_float)]
+              ("comp_kind", C.c_int32), ("comp_a", C.c_float), ("comp_b", C.c_float),
+              ("stochastic_rounding_float16", C.c_int32)]
 
 
 class TableCfg(C.Structure):  # mono_table_cfg

@@ -49,6 +49,8 @@ struct SegDev {
   float beta1, beta2;
   int comp_kind;    // serving tables: MONO_COMP_*
   float cq0, cq1;   // FixedR8: step, half step; OneBit: amplitude, scale
+  int sr_pre;       // fp16 stochastic rounding: first decorated segment before this one, or -1
+  int sr_post;      // ... this segment is decorated
 };
 
 // per-element optimizer state slots of a row: norm | (FTRL) zero; n; accum | accum_update;
@@ -81,6 +83,7 @@ struct TableDev {  // passed to kernels by value
   int dim, row_floats, n_seg;
   int default_expire_days;
   int serving;  // MONO_ENTRY_SERVING: writes store compressor round trips (comp_q)
+  int any_sr;   // some segment rounds to fp16 stochastically (generic path, no long segments)
   uint64_t seed;
   const int32_t* slot_expire;  // int32[32768] or nullptr
   SegDev seg[kMaxSeg];
@@ -528,6 +531,38 @@ __device__ __forceinline__ float comp_q(const SegDev& c, float v) {
   return v;
 }
 
+// stochastic_rounding.h:27-37: vf goes to the binary16 neighbour above with probability
+// (vf - down) / (up - down). The neighbours come from the to-nearest conversion: that result is
+// one of them, the other is the next half on the far side (= float2half<round_toward_infinity /
+// round_toward_neg_infinity> of the reference's half.hpp; the oracle's restatement is checked
+// against that header, this one against the oracle).
+__device__ __forceinline__ float half_neighbour(float v, bool up) {
+  if (isnan(v)) return v;
+  const __half hn = __float2half_rn(v);
+  const float near = __half2float(hn);
+  if (near == v) return near;
+  if (up ? near > v : near < v) return near;
+  const unsigned short h = __half_as_ushort(hn);
+  const bool neg = (h & 0x8000u) != 0;
+  unsigned short o;
+  if (up) o = neg ? ((h & 0x7FFFu) ? (unsigned short)(h - 1) : (unsigned short)0x0001u) : (unsigned short)(h + 1);
+  else o = neg ? (unsigned short)(h + 1) : ((h & 0x7FFFu) ? (unsigned short)(h - 1) : (unsigned short)0x8001u);
+  return __half2float(__ushort_as_half(o));
+}
+__device__ __forceinline__ float stochastic_round(float vf, float p) {
+  const float up = half_neighbour(vf, true), down = half_neighbour(vf, false);
+  return (p <= __fdiv_rn(vf - down, up - down)) ? up : down;
+}
+// p: counter-based (table seed, global_step, batch position of the occurrence, element, stage);
+// the reference's thread-local sequence cannot be pinned (see oracle.cc, sr_uniform)
+__device__ __forceinline__ float sr_uniform(uint64_t seed, long long gstep, uint32_t pos, int e,
+                                            int stage) {
+  uint64_t x = mix64(seed ^ 0x5bd1e995u) ^ mix64((uint64_t)gstep + 0x9e3779b97f4a7c15ULL);
+  x = mix64(x ^ ((uint64_t)pos << 32 | (uint32_t)e)) ^ mix64((uint64_t)stage + 77);
+  const uint32_t u = (uint32_t)(mix64(x) >> 32);
+  return __fdiv_rn((float)u, 4294967296.f);
+}
+
 // third state slot + per-row scalars (generic path only; the specialised kernels pass a dummy)
 struct OptX {
   float s2 = 0.f, b1p = 0.f, b2p = 0.f;
@@ -746,7 +781,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
     }
   }
 
-  if (end - first > kLongSeg && D <= kLongMaxDim && !t.serving &&
+  if (end - first > kLongSeg && D <= kLongMaxDim && !t.serving && !t.any_sr &&
       (a.mode == MODE_ASSIGN_ADD || a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP)) {
     if (sub == 0) enqueue_long(a, first, end, key, slot, fresh ? 1u : 0u);
     return;
@@ -797,6 +832,11 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
         st1_off[q] = 2 * D + e0 + q;
       }
     }
+    if (OPTK == OPTK_MULTI && t.any_sr) {  // the rounding decorator calls Optimize without the step
+#pragma unroll
+      for (int q = 0; q < V; ++q)
+        if (t.seg[segi[q]].sr_post) ox[q].gstep = 0;
+    }
     const bool need_state = a.mode >= MODE_OPT_SEQ;
     if (fresh) {
 #pragma unroll
@@ -846,8 +886,14 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
         float g[V];
         vload<V>(g, a.src + (uint64_t)a.sidx[p] * D + e0);
 #pragma unroll
-        for (int q = 0; q < V; ++q)
-          opt_step(kind[q], t.seg[segi[q]], a.lr[segi[q]], g[q], w[q], s0[q], s1[q], ox[q]);
+        for (int q = 0; q < V; ++q) {
+          const SegDev& sg = t.seg[segi[q]];
+          if (OPTK == OPTK_MULTI && t.any_sr && sg.sr_pre >= 0)
+            w[q] = stochastic_round(w[q], sr_uniform(t.seed, a.global_step, a.sidx[p], e0 + q, sg.sr_pre));
+          opt_step(kind[q], sg, a.lr[segi[q]], g[q], w[q], s0[q], s1[q], ox[q]);
+          if (OPTK == OPTK_MULTI && t.any_sr && sg.sr_post)
+            w[q] = stochastic_round(w[q], sr_uniform(t.seed, a.global_step, a.sidx[p], e0 + q, segi[q]));
+        }
       }
     } else {  // MODE_OPT_DEDUP: in-order sum (bridge :251-266), then one step
       float acc[V];
@@ -868,9 +914,16 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
 #pragma unroll
         for (int q = 0; q < V; ++q) acc[q] = acc[q] + g[q];
       }
+      const uint32_t pos0 = first == j ? idx0 : a.sidx[first];
 #pragma unroll
-      for (int q = 0; q < V; ++q)
-        opt_step(kind[q], t.seg[segi[q]], a.lr[segi[q]], acc[q], w[q], s0[q], s1[q], ox[q]);
+      for (int q = 0; q < V; ++q) {
+        const SegDev& sg = t.seg[segi[q]];
+        if (OPTK == OPTK_MULTI && t.any_sr && sg.sr_pre >= 0)
+          w[q] = stochastic_round(w[q], sr_uniform(t.seed, a.global_step, pos0, e0 + q, sg.sr_pre));
+        opt_step(kind[q], sg, a.lr[segi[q]], acc[q], w[q], s0[q], s1[q], ox[q]);
+        if (OPTK == OPTK_MULTI && t.any_sr && sg.sr_post)
+          w[q] = stochastic_round(w[q], sr_uniform(t.seed, a.global_step, pos0, e0 + q, segi[q]));
+      }
     }
     // --- store
     vstore<V>(row + e0, w);
@@ -1474,7 +1527,8 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
   const bool walks =
       a.mode == MODE_ASSIGN_ADD || a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP;
   // (a serving entry re-encodes after every add: its segments are walked whole, never chunked)
-  const bool allow_long = walks && a.n > kLongSeg && t->d.dim <= kLongMaxDim && !t->d.serving;
+  const bool allow_long = walks && a.n > kLongSeg && t->d.dim <= kLongMaxDim && !t->d.serving &&
+                          !t->d.any_sr;
   const unsigned lgrid = (unsigned)std::min<int64_t>(a.n / kLongSeg + 1, 1024);
   if (a.from_keys) {
     // filter path: the sub-group kernel resolves / gates / claims and feeds the long queue
@@ -1735,6 +1789,11 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
     sd.momentum = c.momentum; sd.epsilon = c.epsilon; sd.rho = c.averaging_ratio;
     sd.conf_lr = c.learning_rate; sd.nesterov = c.use_nesterov;
     sd.beta1 = c.beta1; sd.beta2 = c.beta2;
+    sd.sr_post = (!serving && c.stochastic_rounding_float16) ? 1 : 0;
+    sd.sr_pre = -1;
+    for (int z = s - 1; z >= 0; --z)
+      if (d.seg[z].sr_post) sd.sr_pre = z;  // ends at the FIRST decorated segment before s
+    if (sd.sr_post) d.any_sr = 1;
     sd.comp_kind = serving ? c.comp_kind : MONO_COMP_FP32;
     sd.cq0 = sd.cq1 = 0.f;
     if (sd.comp_kind == MONO_COMP_FIXED_R8) {  // fake_quantizer.h:28-29: step = r / 128, half step
@@ -1752,7 +1811,8 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
   d.default_expire_days = cfg->default_expire_days;
   // the three reference-config optimizers have specialised kernels; the rest (and mixes) take
   // the generic per-element path
-  t->opt_tmpl = !serving && cfg->n_segments == 1 && cfg->segments[0].opt_kind <= MONO_OPT_FTRL
+  t->opt_tmpl = !serving && !d.any_sr && cfg->n_segments == 1 &&
+                        cfg->segments[0].opt_kind <= MONO_OPT_FTRL
                     ? cfg->segments[0].opt_kind : OPTK_MULTI;
   // floats per lane: the widest access that still keeps all 8 lanes of a sub-group busy
   t->vec = 1;

@@ -121,6 +121,21 @@ class BatchSoftmaxOptimizer(Optimizer):  # entry.py:207-223, optimizer.proto:160
   kind = OPT_BATCH_SOFTMAX
 
 
+class StochasticRoundingFloat16OptimizerWrapper(Optimizer):  # entry.py:42-50, optimizer.proto:213
+  """Marks the wrapped optimizer's segment for fp16 stochastic rounding of the weights after
+  every step (StochasticRoundingFloat16OptimizerDecorator, stochastic_rounding.h:39-56)."""
+
+  def __init__(self, optimizer: Optimizer):
+    self._optimizer = optimizer
+
+  @property
+  def kind(self):
+    return self._optimizer.kind
+
+  def __repr__(self):
+    return "StochasticRoundingFloat16OptimizerWrapper(%r)" % (self._optimizer,)
+
+
 class _NotImplementedOptimizer(Optimizer):
   """Optimizers whose reference factory throws `optimizer is not implemented yet`
   (group_ftrl_optimizer.cc:25-29, dynamic_wd_adagrad_optimizer.cc:25-29): a table built with one

@@ -85,6 +85,9 @@ class _TableResource:
     _reject_unimplemented_optimizers(table_config)
     for s in table_config.segments:
       o, i = s.opt_config, s.init_config
+      sr16 = isinstance(o, entry.StochasticRoundingFloat16OptimizerWrapper)
+      if sr16:
+        o = o._optimizer
       if not isinstance(o, (entry.SgdOptimizer, entry.AdagradOptimizer, entry.FtrlOptimizer,
                             entry.MomentumOptimizer, entry.RmspropOptimizer,
                             entry.RmspropV2Optimizer, entry.AdadeltaOptimizer,
@@ -106,6 +109,7 @@ class _TableResource:
       seg.use_nesterov = int(bool(getattr(o, "use_nesterov", False)))
       seg.beta1 = getattr(o, "beta1", 0.9)
       seg.beta2 = getattr(o, "beta2", 0.99)
+      seg.stochastic_rounding_float16 = int(sr16)
       comp = s.comp_config
       seg.comp_kind = getattr(comp, "kind", 0) or 0
       if isinstance(comp, entry.FixedR8Compressor):
@@ -467,7 +471,7 @@ def fused_apply_gradient(tables: List, ids, fused_slot_size, id_grads, id_offset
 def _reject_unimplemented_optimizers(table_config):
   """optimizer_factory.cc:50-53,76-78: the reference factory throws for these configs."""
   for s in table_config.segments:
-    o = s.opt_config
+    o = getattr(s.opt_config, "_optimizer", s.opt_config)
     if isinstance(o, entry._NotImplementedOptimizer):
       raise ValueError("optimizer is not implemented yet. %s %r" % (type(o).__name__, o.__dict__))
 

@@ -27,7 +27,8 @@ class SegCfg(C.Structure):
               ("init_b", C.c_float), ("momentum", C.c_float), ("epsilon", C.c_float),
               ("averaging_ratio", C.c_float), ("learning_rate", C.c_float),
               ("use_nesterov", C.c_int32), ("beta1", C.c_float), ("beta2", C.c_float),
-              ("comp_kind", C.c_int32), ("comp_a", C.c_float), ("comp_b", C.c_float)]
+              ("comp_kind", C.c_int32), ("comp_a", C.c_float), ("comp_b", C.c_float),
+              ("stochastic_rounding_float16", C.c_int32)]
 
 
 class TableCfg(C.Structure):
@@ -82,7 +83,7 @@ def _ptr_array(arrs):
 def seg(dim, opt="sgd", init="zeros", init_acc=0.1, weight_decay=0.0, l1=0.0, l2=0.0, beta=0.0,
         init_a=0.0, init_b=0.0, momentum=0.9, epsilon=0.01, averaging_ratio=0.9,
         learning_rate=0.01, use_nesterov=False, beta1=0.9, beta2=0.99, comp="fp32", comp_a=0.0,
-        comp_b=1.0):
+        comp_b=1.0, stochastic_rounding_float16=False):
   ok = {"sgd": OPT_SGD, "adagrad": OPT_ADAGRAD, "ftrl": OPT_FTRL, "momentum": OPT_MOMENTUM,
         "rmsprop": OPT_RMSPROP, "rmspropv2": OPT_RMSPROP_V2, "adadelta": OPT_ADADELTA,
         "adam": OPT_ADAM, "amsgrad": OPT_AMSGRAD, "moving_average": OPT_MOVING_AVERAGE,
@@ -91,7 +92,8 @@ def seg(dim, opt="sgd", init="zeros", init_acc=0.1, weight_decay=0.0, l1=0.0, l2
         "uniform": INIT_UNIFORM}[init]
   return SegCfg(dim, ok, init_acc, weight_decay, l1, l2, beta, ik, init_a, init_b, momentum,
                 epsilon, averaging_ratio, learning_rate, int(bool(use_nesterov)), beta1, beta2,
-                {"fp32": 0, "fp16": 1, "fixed_r8": 2, "one_bit": 3}[comp], comp_a, comp_b)
+                {"fp32": 0, "fp16": 1, "fixed_r8": 2, "one_bit": 3}[comp], comp_a, comp_b,
+                int(bool(stochastic_rounding_float16)))
 
 
 def make_table_cfg(segments, initial_capacity=1, default_expire_days=36500, slot_expire=None,

@@ -50,6 +50,7 @@ struct SegCfg {  // == mono_segment_cfg
   float beta1, beta2;
   int32_t comp_kind;  // serving entries: COMP_*
   float comp_a, comp_b;
+  int32_t stochastic_rounding_float16;  // OptimizerConfig field 4 (optimizer.proto:213)
 };
 
 // floats of optimizer context: SizeBytes() / sizeof(float) of the reference optimizers
@@ -271,6 +272,71 @@ inline float fp16_roundtrip(float v) {
   return res;
 }
 
+// Neighbouring binary16 values of v as floats: the smallest half >= v (up) and the largest
+// half <= v (down), i.e. half.hpp's float2half<round_toward_infinity / round_toward_neg_infinity>
+// followed by half2float (stochastic_rounding.h:28-31); checked against that header in
+// tests/test_serving.py. Built on the to-nearest conversion: that result is one of the two
+// neighbours, the other one is the next half on the far side.
+inline uint16_t half_bits_of_exact(float h) {  // h is exactly representable in binary16
+  uint32_t x;
+  std::memcpy(&x, &h, 4);
+  const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+  const uint32_t ax = x & 0x7FFFFFFFu;
+  if (ax >= 0x7F800000u) return sign | 0x7C00u;
+  if (ax >= 0x38800000u) return sign | (uint16_t)(((ax >> 23) - 112) << 10) | (uint16_t)((ax >> 13) & 0x3FF);
+  float a;
+  std::memcpy(&a, &ax, 4);
+  return sign | (uint16_t)(a * 16777216.0f);
+}
+inline float float_of_half_bits(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31, m = h & 0x3FF;
+  float r;
+  if (e == 31) {
+    const uint32_t x = sign | 0x7F800000u | (m << 13);
+    std::memcpy(&r, &x, 4);
+    return r;
+  }
+  if (e == 0) {
+    r = (float)m * (1.0f / 16777216.0f);
+    uint32_t x;
+    std::memcpy(&x, &r, 4);
+    x |= sign;
+    std::memcpy(&r, &x, 4);
+    return r;
+  }
+  const uint32_t x = sign | ((e + 112) << 23) | (m << 13);
+  std::memcpy(&r, &x, 4);
+  return r;
+}
+inline float half_neighbour(float v, bool up) {
+  if (std::isnan(v)) return v;
+  const float near = fp16_roundtrip(v);
+  if (near == v) return near;
+  if (up ? near > v : near < v) return near;
+  const uint16_t h = half_bits_of_exact(near);
+  const bool neg = (h & 0x8000u) != 0;
+  uint16_t o;
+  if (up) o = neg ? ((h & 0x7FFFu) ? (uint16_t)(h - 1) : (uint16_t)0x0001u) : (uint16_t)(h + 1);
+  else o = neg ? (uint16_t)(h + 1) : ((h & 0x7FFFu) ? (uint16_t)(h - 1) : (uint16_t)0x8001u);
+  return float_of_half_bits(o);
+}
+// stochastic_rounding.h:27-37
+inline float stochastic_round(float vf, float p) {
+  const float vf_up = half_neighbour(vf, true), vf_down = half_neighbour(vf, false);
+  if (p <= (vf - vf_down) / (vf_up - vf_down)) return vf_up;
+  return vf_down;
+}
+// The reference draws p from a thread-local multiply-with-carry sequence (stochastic_rounding.h:
+// 90-107): which number meets which element depends on threads and call order, so it cannot be
+// pinned. Here p is a counter-based hash of (table seed, global_step, position of the occurrence
+// in the batch, element, stage), the same on the GPU; the conversion to [0, 1] is the reference's.
+inline float sr_uniform(uint64_t seed, int64_t gstep, uint32_t pos, int e, int stage) {
+  uint64_t x = mix64(seed ^ 0x5bd1e995u) ^ mix64((uint64_t)gstep + 0x9e3779b97f4a7c15ULL);
+  x = mix64(x ^ ((uint64_t)pos << 32 | (uint32_t)e)) ^ mix64((uint64_t)stage + 77);
+  const uint32_t u = (uint32_t)(mix64(x) >> 32);
+  return static_cast<float>(u) / 4294967296;
+}
+
 // Decode(Encode(v)) of float_compressor.cc:63-137 for one value
 inline float comp_q(const SegCfg& c, float v) {
   if (c.comp_kind == COMP_FP16) return fp16_roundtrip(v);
@@ -361,7 +427,8 @@ struct Table {
   }
 
   // entry_accessor.cc:163-171 -> optimizer_combination.cc:53-63 -> per-segment Optimize
-  void optimize(Entry& e, const float* grad, const float* lrs, int64_t global_step) const {
+  void optimize(Entry& e, const float* grad, const float* lrs, int64_t global_step,
+                uint32_t pos) const {
     for (size_t s = 0; s < segs.size(); ++s) {
       const SegCfg& c = segs[s];
       float* num = e.row.data() + seg_w_off[s];
@@ -455,8 +522,10 @@ struct Table {
         int64_t A;
         std::memcpy(&A, st, sizeof(A));
         float alpha = lr;
-        B = (1 - alpha) * B + alpha * static_cast<float>(global_step - A);
-        A = global_step;
+        // (the rounding decorator calls Optimize without the step: its default 0 arrives here)
+        const int64_t step = c.stochastic_rounding_float16 ? 0 : global_step;
+        B = (1 - alpha) * B + alpha * static_cast<float>(step - A);
+        A = step;
         std::memcpy(st, &A, sizeof(A));
       } else if (c.opt_kind == OPT_MOVING_AVERAGE) {  // moving_average_optimizer.cc:39-47
         for (int i = 0; i < c.dim; ++i) {
@@ -492,6 +561,13 @@ struct Table {
                        : 0.0f;
         }
       }
+      // StochasticRoundingFloat16OptimizerDecorator::Optimize (stochastic_rounding.h:48-56):
+      // every element of the span the segment's optimizer was handed is rounded, and inside
+      // CombinedOptimizer that span runs from the segment's first weight to the END of the
+      // entry (optimizer_combination.cc:58-62: num.subspan(dim_size1_) keeps the tail)
+      if (c.stochastic_rounding_float16)
+        for (int i = seg_w_off[s]; i < dim; ++i)
+          e.row[i] = stochastic_round(e.row[i], sr_uniform(seed, global_step, pos, i, (int)s));
     }
   }
 
@@ -588,6 +664,16 @@ void* orc_table_create(const TableCfg* cfg) {
   return t;
 }
 void orc_table_destroy(void* t) { delete (Table*)t; }
+// half neighbours / stochastic_round over arrays (tests compare them with the reference header)
+void orc_half_up_down(const float* in, float* up, float* down, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    up[i] = half_neighbour(in[i], true);
+    down[i] = half_neighbour(in[i], false);
+  }
+}
+void orc_stochastic_round(const float* in, const float* p, float* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = stochastic_round(in[i], p[i]);
+}
 // Decode(Encode(v)) of one compressor over an array (tests compare it with the reference headers)
 void orc_compress_roundtrip(int kind, float a, float b, const float* in, float* out, int64_t n) {
   SegCfg c{};
@@ -655,8 +741,10 @@ void orc_table_apply_gradients(void* tp, void* fp, const int64_t* ids, const flo
   const int D = t->dim;
   std::vector<int64_t> ids_after;
   std::vector<const float*> grads_after;
+  std::vector<uint32_t> pos_after;  // batch position of the (first) occurrence: rounding stream only
   std::vector<float> cache;
   if (enable_dedup) {
+    std::vector<uint32_t> first_pos;
     cache.resize((size_t)n * D);
     std::unordered_map<int64_t, int64_t> pos;  // id -> unique index (first-occurrence order)
     std::vector<int64_t> uniq;
@@ -667,6 +755,7 @@ void orc_table_apply_gradients(void* tp, void* fp, const int64_t* ids, const flo
         pos.emplace(ids[i], (int64_t)uniq.size());
         std::memcpy(cache.data() + uniq.size() * D, grads + i * D, sizeof(float) * D);
         uniq.push_back(ids[i]);
+        first_pos.push_back((uint32_t)i);
         counts.push_back(1);
       } else {  // ReduceSum(dest, src, dest): dest[j] = dest[j] + src[j], in input order
         float* dest = cache.data() + it->second * D;
@@ -681,18 +770,20 @@ void orc_table_apply_gradients(void* tp, void* fp, const int64_t* ids, const flo
       if (f && !t->m.count(uniq[u]) && f->should_be_filtered(uniq[u], counts[u])) continue;
       ids_after.push_back(uniq[u]);
       grads_after.push_back(cache.data() + u * D);
+      pos_after.push_back(first_pos[u]);
     }
   } else {
     for (int64_t i = 0; i < n; ++i) {
       if (f && !t->m.count(ids[i]) && f->should_be_filtered(ids[i], 1)) continue;
       ids_after.push_back(ids[i]);
       grads_after.push_back(grads + i * D);
+      pos_after.push_back((uint32_t)i);
     }
   }
   for (size_t k = 0; k < ids_after.size(); ++k) {  // cuckoo_embedding_hash_table.cc:198-216
     Entry& e = t->upsert(ids_after[k]);
     e.ts = (uint32_t)req_time;
-    t->optimize(e, grads_after[k], lrs, global_step);
+    t->optimize(e, grads_after[k], lrs, global_step, pos_after[k]);
   }
 }
 

@@ -10,6 +10,8 @@ _counter = itertools.count()
 
 
 def _opt(d):
+  if d.get("sr16"):
+    return entry.StochasticRoundingFloat16OptimizerWrapper(_opt(dict(d, sr16=False)))
   k = d.get("opt", "sgd")
   if k == "sgd":
     return entry.SgdOptimizer()

@@ -12,7 +12,8 @@ def seg_from_dict(d):
                  learning_rate=d.get("learning_rate", 0.01),
                  use_nesterov=d.get("use_nesterov", False), beta1=d.get("beta1", 0.9),
                  beta2=d.get("beta2", 0.99), comp=d.get("comp", "fp32"),
-                 comp_a=d.get("comp_a", 0.0), comp_b=d.get("comp_b", 1.0))
+                 comp_a=d.get("comp_a", 0.0), comp_b=d.get("comp_b", 1.0),
+                 stochastic_rounding_float16=bool(d.get("sr16")))
 
 
 def make_table(cfg):

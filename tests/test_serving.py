@@ -154,3 +154,88 @@ def test_serving_table_restores_a_training_dump(tmp_path):
   o.import_rows(tid, np.ascontiguousarray(trow[:, :12]), tts)
   probe = np.arange(-5, 305, dtype=np.int64)
   assert np.array_equal(o.lookup(probe).view(np.uint32), sv.lookup(probe).view(np.uint32))
+
+
+# ------------------------------------------------------------------ fp16 stochastic rounding
+def test_half_neighbours_and_stochastic_round_against_reference_header():
+  """stochastic_rounding.h:27-37. up / down = float2half<round_toward_(neg_)infinity> of the
+  reference's half.hpp (oracle/_ref), bit for bit incl. overflow, subnormals and signed zeros;
+  the draw itself (a thread-local sequence in the reference) is not pinnable."""
+  x = _samples()
+  up, down = np.empty_like(x), np.empty_like(x)
+  cpu.lib().orc_half_up_down(C.c_void_p(x.ctypes.data), C.c_void_p(up.ctypes.data),
+                             C.c_void_p(down.ctypes.data), C.c_int64(x.size))
+  fin = np.isfinite(x)
+  assert (up[fin] >= x[fin]).all() and (down[fin] <= x[fin]).all()
+  with np.errstate(over="ignore", invalid="ignore"):
+    exact = x.astype(np.float16).astype(np.float32) == x
+  assert np.array_equal(up[exact & fin], x[exact & fin]) and np.array_equal(down[exact & fin], x[exact & fin])
+  if os.path.exists(REF):
+    ref = C.CDLL(REF)
+    ru, rd = np.empty_like(x), np.empty_like(x)
+    ref.ref_half_up_down(C.c_void_p(x.ctypes.data), C.c_void_p(ru.ctypes.data),
+                         C.c_void_p(rd.ctypes.data), C.c_int64(x.size))
+    nan = np.isnan(x)
+    assert np.array_equal(ru[~nan].view(np.uint32), up[~nan].view(np.uint32))
+    assert np.array_equal(rd[~nan].view(np.uint32), down[~nan].view(np.uint32))
+  # the rule: p <= (v - down) / (up - down) -> up; a representable value is returned unchanged
+  v = np.float32([0.1, 0.1, 0.1, 0.5, -0.1, 70000.0])
+  p = np.float32([0.0, 0.3, 1.0, 0.7, 0.5, 0.5])
+  out = np.empty_like(v)
+  cpu.lib().orc_stochastic_round(C.c_void_p(v.ctypes.data), C.c_void_p(p.ctypes.data),
+                                 C.c_void_p(out.ctypes.data), C.c_int64(v.size))
+  h = np.float32(0.1).astype(np.float16).astype(np.float32)   # 0.0999755859375 < 0.1
+  hi = np.nextafter(np.float16(h), np.float16(1)).astype(np.float32)
+  frac = (np.float32(0.1) - h) / (hi - h)
+  assert out[0] == hi and out[1] == (hi if 0.3 <= frac else h) and out[2] == h
+  assert out[3] == 0.5 and out[4] in (-h, -hi) and out[5] == 65504.0
+  # unbiased on average
+  n = 200_000
+  v = np.full(n, 0.1, np.float32)
+  p = np.random.Generator(np.random.PCG64(3)).random(n, dtype=np.float32)
+  out = np.empty_like(v)
+  cpu.lib().orc_stochastic_round(C.c_void_p(v.ctypes.data), C.c_void_p(p.ctypes.data),
+                                 C.c_void_p(out.ctypes.data), C.c_int64(n))
+  assert abs(out.astype(np.float64).mean() - 0.1) < 2e-7 * 50
+
+
+SR16 = {"seed": 17, "segments": [
+    {"dim": 2, "opt": "adagrad", "init": "uniform", "init_a": -0.1, "init_b": 0.1},
+    {"dim": 3, "opt": "sgd", "sr16": True, "init": "uniform", "init_a": -0.1, "init_b": 0.1},
+    {"dim": 2, "opt": "adam", "init": "uniform", "init_a": -0.1, "init_b": 0.1},
+    {"dim": 1, "opt": "ftrl", "sr16": True, "beta": 1.0}]}
+
+
+def test_rounding_span_runs_to_the_end_of_the_entry():
+  """Inside CombinedOptimizer the decorated segment's span keeps the tail of the entry
+  (optimizer_combination.cc:58-62): segment 1's rounding also rounds segments 2 and 3 — before
+  their own steps; segment 0 is never rounded."""
+  t = oracle_backend.make_table(SR16)
+  ids = np.array([3], np.int64)
+  t.apply_gradients(ids, np.full((1, 8), 0.25, np.float32), [0.01] * 4, global_step=5)
+  _, rows, _ = t.export()
+  w = rows[0][:8]
+  is_half = lambda a: np.array_equal(a.astype(np.float16).astype(np.float32), a)
+  assert not is_half(w[:2]) and is_half(w[2:5]) and is_half(w[7:8])
+  assert not is_half(w[5:7])      # Adam stepped from the rounded value, result not rounded
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dedup", [False, True])
+def test_stochastic_rounding_table_matches_oracle(dedup):
+  from tests import hip_backend
+  o, h = oracle_backend.make_table(SR16), hip_backend.make_table(SR16)
+  rng = np.random.Generator(np.random.PCG64(41 + dedup))
+  probe = np.arange(-20, 320, dtype=np.int64)
+  for step in range(5):
+    n = 3000
+    ids = rng.zipf(1.4, n).astype(np.int64) % 300 - 10
+    if step == 2:
+      ids[::3] = 4   # 1000 steps on one entry, each with its own draws
+    g = rng.normal(0, 0.3, (n, 8)).astype(np.float32)
+    for t in (o, h):
+      t.apply_gradients(ids, g, [0.01, 0.02, 0.03, 0.04], req_time=9 + step, global_step=100 + step,
+                        enable_dedup=dedup)
+    assert np.array_equal(o.lookup(probe).view(np.uint32), h.lookup(probe).view(np.uint32)), step
+  a, b = o.export(), h.export()
+  assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
