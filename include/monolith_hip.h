@@ -174,6 +174,13 @@ int mono_table_apply_gradients(void* table, void* filter, const int64_t* ids, co
 int mono_table_size(void* table, int64_t* h_size, void* stream);
 /* EmbeddingHashTableInterface::Contains (embedding_hash_table_interface.h:107): out[i] in {0,1}. */
 int mono_table_contains(void* table, const int64_t* ids, int64_t n, uint8_t* out, void* stream);
+/* HashTableLookupEntryOp (ops/hash_table_lookup_op.cc:79-107) ->
+ * CuckooEmbeddingHashTable::LookupEntry (cuckoohash/cuckoo_embedding_hash_table.cc:162-171): the
+ * whole entry of every id: rows[n, row_floats] (weights | optimizer context), ts[n], found[n]
+ * (0 = not in the table: the op returns an empty string for it). Serialization of the EntryDump
+ * is host work (monolith_amd/checkpoint.py). */
+int mono_table_lookup_entry(void* table, const int64_t* ids, int64_t n, float* rows, uint32_t* ts,
+                            uint8_t* found, void* stream);
 /* EmbeddingHashTableInterface::Clear (cuckoo_embedding_hash_table.cc:270-273). */
 int mono_table_clear(void* table, void* stream);
 /* CuckooEmbeddingHashTable::Evict (cuckoo_embedding_hash_table.cc:220-233). */

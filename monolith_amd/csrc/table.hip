@@ -338,6 +338,26 @@ __global__ void __launch_bounds__(256) k_contains(TableDev t, const int64_t* __r
   }
 }
 
+// LookupEntry (cuckoo_embedding_hash_table.cc:162-171): the whole entry of every id that is in the
+// table — weights, optimizer context, timestamp — and whether it was found.
+__global__ void __launch_bounds__(256) k_lookup_entry(TableDev t, const int64_t* __restrict__ ids,
+                                                      int64_t n, float* __restrict__ rows,
+                                                      uint32_t* __restrict__ ts,
+                                                      uint8_t* __restrict__ found) {
+  const int sub = lane_sub(), gshift = lane_gshift();
+  const int R = t.row_floats;
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8; i < n; i += ngroups) {
+    const uint32_t slot = group_find(t, ids[i], sub, gshift);
+    const float* row = t.rows + (uint64_t)slot * R;
+    for (int e = sub; e < R; e += 8) rows[i * R + e] = slot != kNoSlot ? row[e] : 0.f;
+    if (sub == 0) {
+      found[i] = slot != kNoSlot;
+      ts[i] = slot != kNoSlot ? t.ts[slot] : 0u;
+    }
+  }
+}
+
 // Write path, step 1 (no filter): resolve every occurrence to its slot, inserting + initialising
 // missing keys (cuckoo_embedding_hash_table.cc:284-291). Emits (slot, occurrence index) pairs.
 __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t* __restrict__ ids,
@@ -1982,6 +2002,17 @@ int mono_table_contains(void* table, const int64_t* ids, int64_t n, uint8_t* out
   Table* t = (Table*)table;
   hipLaunchKernelGGL(k_contains, dim3(grid_for(n, 32)), dim3(256), 0, (hipStream_t)stream, t->d, ids,
                      n, out);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int mono_table_lookup_entry(void* table, const int64_t* ids, int64_t n, float* rows, uint32_t* ts,
+                            uint8_t* found, void* stream) {
+  MONO_REQUIRE(table && (n == 0 || (ids && rows && ts && found)), "mono_table_lookup_entry: null argument");
+  if (n == 0) return 0;
+  Table* t = (Table*)table;
+  hipLaunchKernelGGL(k_lookup_entry, dim3(grid_for(n, 32)), dim3(256), 0, (hipStream_t)stream, t->d,
+                     ids, n, rows, ts, found);
   MONO_HIP(hipGetLastError());
   return 0;
 }

@@ -230,6 +230,27 @@ class HashTable(BaseHashTable):
                                           _lib.vp(out), _lib.stream_ptr()))
     return out
 
+  def lookup_entry(self, ids) -> List[bytes]:
+    """hash_table_ops.py:278-281 -> HashTableLookupEntryOp: one serialized EntryDump per id
+    (without the id field: Save() of the accessor does not set it), b"" for ids not in the table."""
+    from monolith_amd import checkpoint
+    ids = _ids(ids)
+    n = int(ids.numel())
+    t = self._table
+    if t.serving:  # entry_accessor.cc:85-87
+      raise RuntimeError("ServingEntryAccessor doesn't support Save")
+    rows = torch.empty((n, t.row_floats), dtype=torch.float32, device=ids.device)
+    ts = torch.empty(n, dtype=torch.int32, device=ids.device)
+    found = torch.empty(n, dtype=torch.uint8, device=ids.device)
+    _lib.check(_lib.lib.mono_table_lookup_entry(t.h, _lib.vp(ids), C.c_int64(n), _lib.vp(rows),
+                                                _lib.vp(ts), _lib.vp(found), _lib.stream_ptr()))
+    layout = checkpoint.DumpLayout.from_table_config(t.config)
+    rows_h, ts_h, found_h = rows.cpu().numpy(), ts.cpu().numpy().view(np.uint32), found.cpu().numpy()
+    out = [b""] * n
+    for i in np.nonzero(found_h)[0]:
+      out[i] = layout._encode_one(0, rows_h[i], int(ts_h[i]))[9:]   # drop `09 <id>`
+    return out
+
   def apply_gradients(self, ids, grads, global_step, use_multi_threads=False, enable_dedup=False,
                       req_time=None) -> "HashTable":
     ids, grads = _ids(ids), _f32(grads)
@@ -466,6 +487,37 @@ def fused_apply_gradient(tables: List, ids, fused_slot_size, id_grads, id_offset
         if cnt:
           t._record_touched(ids[lo:lo + cnt])
   return tables
+
+
+def extract_slot_from_entry(entry: Sequence[bytes], fid_v2: bool = True) -> np.ndarray:
+  """hash_table_ops.py:692-693 -> ExtractSlotFromEntryOp (ops/hash_table/misc_ops.cc:113-142):
+  slot of the id inside each serialized EntryDump (slot_id_v2 = bits 48..62, v1 = fid >> 54,
+  reader_util.h:33-37); an unparsable / id-less dump reads as id 0."""
+  from monolith_amd import checkpoint
+  out = np.zeros(len(entry), np.int32)
+  for i, b in enumerate(entry):
+    b, fid, pos = bytes(b), 0, 0
+    try:
+      while pos < len(b):  # EntryDump.id = field 1, sfixed64 (embedding_hash_table.proto:45-50)
+        tag, pos = checkpoint._read_varint(b, pos)
+        wt = tag & 7
+        if tag == 0x09:
+          fid = int.from_bytes(b[pos:pos + 8], "little")
+        if wt == 1:
+          pos += 8
+        elif wt == 5:
+          pos += 4
+        elif wt == 0:
+          _, pos = checkpoint._read_varint(b, pos)
+        elif wt == 2:
+          ln, pos = checkpoint._read_varint(b, pos)
+          pos += ln
+        else:
+          break
+    except ValueError:  # "Fail to parse entry dump." is only logged there; the id read so far counts
+      pass
+    out[i] = ((fid >> 48) & 0x7FFF) if fid_v2 else (fid >> 54)
+  return out
 
 
 def _reject_unimplemented_optimizers(table_config):

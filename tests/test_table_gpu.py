@@ -270,3 +270,35 @@ def test_lookup_slot_cache_hazards():
   hi, hrows, hts = h.export()
   assert np.array_equal(oi, hi) and np.array_equal(ots, hts)
   assert np.array_equal(orows.view(np.uint32), hrows.view(np.uint32))
+
+
+def test_lookup_entry_and_extract_slot():
+  """hash_table_ops_test.py:100-114 (entries of ids 0..2 parse, id 3 -> b""),
+  embedding_hash_table_test.h:78-93 (the dump of an SGD dim-1 entry holding 1.0, byte for byte:
+  no id field), hash_table_ops_test.py:1190-1194 (slot of 1 << 48 is 1)."""
+  import struct
+  from monolith_amd import checkpoint as ck, hash_table_ops as hto
+  t = hto.test_hash_table(1)
+  t = t.assign(torch.tensor([0, 1, 2], device="cuda"), torch.tensor([[0.1], [0.2], [0.3]], device="cuda"))
+  es = t.lookup_entry(torch.tensor([0, 1, 2, 3], device="cuda"))
+  assert es[3] == b""
+  layout = ck.DumpLayout([(1, ck.SGD)])
+  for e, v in zip(es[:3], (0.1, 0.2, 0.3)):
+    rid, row, ts = layout._decode_one(e)
+    assert rid == 0 and ts == 0 and row[0] == np.float32(v)
+  t2 = hto.test_hash_table(1)
+  t2 = t2.assign(torch.tensor([-10], device="cuda"), torch.tensor([[1.0]], device="cuda"))
+  (e,) = t2.lookup_entry(torch.tensor([-10], device="cuda"))
+  assert e == b"\x15" + struct.pack("<f", 1.0) + b"\x1a\x04\x0a\x02\x12\x00" + b"\x20\x00"
+  # a stateful entry: Adagrad accumulator and timestamp ride along
+  t3 = hto.test_hash_table(2, use_adagrad=True, learning_rate=0.1)
+  ids = torch.tensor([5, 9], device="cuda")
+  t3 = t3.apply_gradients(ids, torch.ones((2, 2), device="cuda"), global_step=0, req_time=1234)
+  e5, e7 = t3.lookup_entry(torch.tensor([5, 7], device="cuda"))
+  assert e7 == b""
+  rid, row, ts = ck.DumpLayout([(2, ck.ADAGRAD)])._decode_one(e5)
+  _, rows, tss = t3.save_as_tensor()
+  assert ts == 1234 and np.array_equal(row, rows.cpu().numpy()[0])
+  entry = b"\x09" + struct.pack("<q", 1 << 48)
+  assert hto.extract_slot_from_entry([entry, b"", b"\x15\x00\x00\x80\x3f" + entry]).tolist() == [1, 0, 1]
+  assert hto.extract_slot_from_entry([b"\x09" + struct.pack("<q", 3 << 54)], fid_v2=False).tolist() == [3]
