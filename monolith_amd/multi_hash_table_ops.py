@@ -106,6 +106,18 @@ class MultiHashTable(BaseMultiTypeHashTable):
     flat_grad = self.get_flat_value({k: v[1] for k, v in slot_to_id_and_grad.items()})
     return self.raw_apply_gradients(ragged_id, flat_grad, global_step, req_time)
 
+  def lookup_entry(self, slot_to_id, enable_inter_table_parallelism: bool = False):
+    raise NotImplementedError("")  # multi_hash_table_ops.py:362-366: the reference raises too
+
+  # multi_hash_table_ops.py:410-429: declared and left unimplemented by the reference
+  def fused_lookup(self, ids, fused_slot_size, num_of_shards: int):
+    raise NotImplementedError("")
+
+  def fused_apply_gradient(self, ids, fused_slot_size, id_grads, id_offsets, grad_offsets,
+                           global_step, req_time, num_of_shards: int,
+                           enable_grad_accumulation: bool = False):
+    raise NotImplementedError("")
+
   def as_op(self, *args, **kwargs):
     return self._tables
 
