@@ -317,12 +317,24 @@ def main():
                                                    C.c_int64(n), lrs, C.c_int(1), C.c_int64(99),
                                                    C.c_int64(i), C.c_int(1), sp))
     _lib.check(_lib.lib.mono_table_last_phase_ms(h, ms3))
+    # k_apply alone (events on the auxiliary stream it runs on, beside k_apply_long); a batch
+    # without hot keys has no such launch: the phase time stands in
+    ka = C.c_float(0)
+    if _lib.lib.mono_table_last_apply_kernel_ms(h, C.byref(ka)) != 0:
+      ka = C.c_float(float("nan"))
     torch.cuda.synchronize()
     lk.append(ev0.elapsed_time(ev1))
-    ph.append([ms3[0], ms3[1], ms3[2]])
+    ph.append([ms3[0], ms3[1], ms3[2], ka.value])
   _lib.check(_lib.lib.mono_table_profile(h, 0))
   lk_ms = float(np.mean(lk[2:]))
-  find_ms, sort_ms, apply_ms = [float(x) for x in np.mean(np.array(ph[2:]), axis=0)]
+  find_ms, sort_ms, apply_ms, kapply_ms = [float(x) for x in np.mean(np.array(ph[2:]), axis=0)]
+  # occurrences / keys that k_apply_long serves instead (segments longer than 96, table.hip kLongSeg)
+  n_long, u_long = [], []
+  for b in pool:
+    cnt = torch.unique(b, return_counts=True)[1]
+    n_long.append(float(cnt[cnt > 96].sum().item()))
+    u_long.append(float((cnt > 96).sum().item()))
+  n_long, u_long = float(np.mean(n_long)), float(np.mean(u_long))
 
   # algorithmic bytes (SURVEY.md §8d, D = 16, Adagrad): lookup 144 B / occurrence;
   # update 72 B / occurrence + 268 B / unique FID  (u/n measured on the stream)
@@ -335,8 +347,12 @@ def main():
       "k_lookup": (lk_ms, lookup_bytes),
       "k_claim_pending": (find_ms, n * (8 + 8 + 4) + n * 4),
       "radix_sort(slot,idx)": (sort_ms, 0),
-      "k_apply": (apply_ms, n * 4 * D + uniq * n * (2 * (4 * D + 4 * D) + 4)),
+      "apply phase": (apply_ms, n * 4 * D + uniq * n * (2 * (4 * D + 4 * D) + 4)),
   }
+  if kapply_ms == kapply_ms:  # the kernel alone: what rocprofv3 reports as mono::k_apply<2, 1>
+    kern["k_apply"] = (kapply_ms, (n - n_long) * 4 * D + (uniq * n - u_long) * (2 * (4 * D + 4 * D) + 4))
+  else:
+    kern["k_apply"] = kern["apply phase"]
   dom = max(("k_lookup", "k_claim_pending", "k_apply"), key=lambda k: kern[k][0])
   achieved = kern[dom][1] / (kern[dom][0] * 1e-3) / 1e9
   step_gbs = (lookup_bytes + update_bytes) / (ms_per_step * 1e-3) / 1e9
@@ -344,15 +360,16 @@ def main():
   # separate rocprofv3 --pmc runs of this same command; calibration note in the summary file)
   traffic, traffic_src = None, None
   try:
-    with open(os.path.join(ROOT, "profiles", "r01_g_pmc_summary.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r01_h_pmc_summary.json")) as f:
       pmc = json.load(f)["kernels"]
     members = {"k_lookup": ["mono::k_lookup<4>"], "k_claim_pending": ["mono::k_claim_pending"],
-               "k_apply": ["mono::k_classify", "mono::k_apply<2, 1>", "mono::k_apply_long<1, 3>",
+               "k_apply": ["mono::k_apply<2, 1>"] if kapply_ms == kapply_ms else
+                          ["mono::k_classify", "mono::k_apply<2, 1>", "mono::k_apply_long<1, 3>",
                            "mono::k_combine<1>"]}[dom]
     if args.batch == 65536 and args.rows == 1e8 and args.skew == 3.0:
       traffic = sum((pmc[m]["FETCH_SIZE_KB_last_launch"] + pmc[m]["WRITE_SIZE_KB_last_launch"]) *
                     1024.0 for m in members)
-      traffic_src = "profiles/r01_g_pmc_summary.json (" + " + ".join(members) + ")"
+      traffic_src = "profiles/r01_h_pmc_summary.json (" + " + ".join(members) + ")"
   except (OSError, KeyError, ValueError):
     pass
 
@@ -370,8 +387,11 @@ def main():
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                    "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                    "traffic_source": traffic_src, "algorithmic_bytes": kern[dom][1],
-                   "kernel_note": "k_apply = apply phase: k_classify, then k_apply (short "
-                                  "segments) beside k_apply_long (hot keys) + k_combine",
+                   "kernel_note": "k_apply = the sub-group apply kernel alone (segments of <= 96 "
+                                  "occurrences), timed with HIP events on the stream it runs on; "
+                                  "'apply phase' = k_classify, then k_apply beside k_apply_long "
+                                  "(hot keys) + k_combine, on the caller's stream",
+                   "long_segment_occurrences": n_long, "long_segment_keys": u_long,
                    "random_64B_line_ceiling_GBps": 3000.0,
                    "kernel_ms": {k: v[0] for k, v in kern.items()},
                    "step_algorithmic_GBps": step_gbs, "step_frac": step_gbs / HBM_PEAK_GBS},

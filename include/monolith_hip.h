@@ -204,6 +204,10 @@ int mono_table_import(void* table, const int64_t* ids, const float* rows, const 
  * h_ms[3] = {resolve slots (find/claim), group (radix sort), apply rows}. */
 int mono_table_profile(void* table, int enable);
 int mono_table_last_phase_ms(void* table, float* h_ms);
+/* Duration of the sub-group apply kernel (k_apply) of the last write call ALONE, from HIP events
+ * on the auxiliary stream it is launched on (it runs beside k_apply_long): the figure that is set
+ * against rocprofv3's per-kernel average. Profiling must be on. */
+int mono_table_last_apply_kernel_ms(void* table, float* h_ms);
 /* Floats per stored row: dim + optimizer state. */
 int mono_table_row_floats(void* table);
 

@@ -109,6 +109,8 @@ struct Table {
   // optional per-phase timing of the write path (mono_table_profile)
   bool profile = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_k[2] = {nullptr, nullptr};  // around k_apply alone, on the stream it runs on
+  bool ev_k_valid = false;
   // fork / join of the long-segment kernel beside the sub-group kernel
   hipStream_t aux = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -1584,7 +1586,12 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
   MONO_HIP(hipEventRecord(t->ev_fork, st));
   launch_long_o(t, a, lgrid, st);
   MONO_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev_k[0], t->aux));
   launch_short(t, a, t->aux);
+  if (t->profile) {
+    MONO_HIP(hipEventRecord(t->ev_k[1], t->aux));
+    t->ev_k_valid = true;
+  }
   MONO_HIP(hipEventRecord(t->ev_join, t->aux));
   MONO_HIP(hipStreamWaitEvent(st, t->ev_join, 0));
   return 0;
@@ -1880,6 +1887,8 @@ int mono_table_destroy(void* table) {
   t->ws.release();
   for (int i = 0; i < 4; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
+  for (int i = 0; i < 2; ++i)
+    if (t->ev_k[i]) (void)hipEventDestroy(t->ev_k[i]);
   if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
   if (t->ev_join) (void)hipEventDestroy(t->ev_join);
   if (t->aux) (void)hipStreamDestroy(t->aux);
@@ -1892,7 +1901,10 @@ int mono_table_profile(void* table, int enable) {
   Table* t = (Table*)table;
   if (enable && !t->ev[0])
     for (int i = 0; i < 4; ++i) MONO_HIP(hipEventCreate(&t->ev[i]));
+  if (enable && !t->ev_k[0])
+    for (int i = 0; i < 2; ++i) MONO_HIP(hipEventCreate(&t->ev_k[i]));
   t->profile = enable != 0;
+  t->ev_k_valid = false;
   return 0;
 }
 
@@ -1902,6 +1914,17 @@ int mono_table_last_phase_ms(void* table, float* h_ms) {
   MONO_REQUIRE(t->profile && t->ev[0], "mono_table_last_phase_ms: profiling is off");
   MONO_HIP(hipEventSynchronize(t->ev[3]));
   for (int i = 0; i < 3; ++i) MONO_HIP(hipEventElapsedTime(&h_ms[i], t->ev[i], t->ev[i + 1]));
+  return 0;
+}
+
+int mono_table_last_apply_kernel_ms(void* table, float* h_ms) {
+  MONO_REQUIRE(table && h_ms, "mono_table_last_apply_kernel_ms: null argument");
+  Table* t = (Table*)table;
+  MONO_REQUIRE(t->profile && t->ev_k_valid,
+               "mono_table_last_apply_kernel_ms: no timed k_apply launch (profiling off, or the "
+               "last write call had no long segments and ran k_apply on the caller's stream)");
+  MONO_HIP(hipEventSynchronize(t->ev_k[1]));
+  MONO_HIP(hipEventElapsedTime(h_ms, t->ev_k[0], t->ev_k[1]));
   return 0;
 }
 
