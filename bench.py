@@ -317,8 +317,8 @@ def main():
                                                    C.c_int64(n), lrs, C.c_int(1), C.c_int64(99),
                                                    C.c_int64(i), C.c_int(1), sp))
     _lib.check(_lib.lib.mono_table_last_phase_ms(h, ms3))
-    # k_apply alone (events on the auxiliary stream it runs on, beside k_apply_long); a batch
-    # without hot keys has no such launch: the phase time stands in
+    # k_apply alone (events on the auxiliary stream it runs on, beside k_apply_long); should the
+    # library report no such launch, the phase time stands in
     ka = C.c_float(0)
     if _lib.lib.mono_table_last_apply_kernel_ms(h, C.byref(ka)) != 0:
       ka = C.c_float(float("nan"))

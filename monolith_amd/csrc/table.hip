@@ -1921,8 +1921,8 @@ int mono_table_last_apply_kernel_ms(void* table, float* h_ms) {
   MONO_REQUIRE(table && h_ms, "mono_table_last_apply_kernel_ms: null argument");
   Table* t = (Table*)table;
   MONO_REQUIRE(t->profile && t->ev_k_valid,
-               "mono_table_last_apply_kernel_ms: no timed k_apply launch (profiling off, or the "
-               "last write call had no long segments and ran k_apply on the caller's stream)");
+               "mono_table_last_apply_kernel_ms: no timed k_apply launch (profiling off, or no "
+               "write call since it was switched on forked k_apply: 96 ids or fewer, a filter)");
   MONO_HIP(hipEventSynchronize(t->ev_k[1]));
   MONO_HIP(hipEventElapsedTime(h_ms, t->ev_k[0], t->ev_k[1]));
   return 0;

@@ -302,3 +302,29 @@ def test_lookup_entry_and_extract_slot():
   entry = b"\x09" + struct.pack("<q", 1 << 48)
   assert hto.extract_slot_from_entry([entry, b"", b"\x15\x00\x00\x80\x3f" + entry]).tolist() == [1, 0, 1]
   assert hto.extract_slot_from_entry([b"\x09" + struct.pack("<q", 3 << 54)], fid_v2=False).tolist() == [3]
+
+
+def test_apply_kernel_timing_hook():
+  """mono_table_profile / mono_table_last_phase_ms / mono_table_last_apply_kernel_ms: the kernel
+  timing exists exactly when the write call forked k_apply onto the auxiliary stream (batches of
+  more than 96 ids, which may hold a long segment), and fails loudly otherwise."""
+  import ctypes as C
+  from monolith_amd import _lib, hash_table_ops as hto
+  t = hto.test_hash_table(4, use_adagrad=True, learning_rate=0.1)
+  h = t.table.h
+  ms3, ka = (C.c_float * 3)(), C.c_float(0)
+  assert _lib.lib.mono_table_last_phase_ms(h, ms3) != 0          # profiling is off
+  _lib.check(_lib.lib.mono_table_profile(h, 1))
+  ids = torch.arange(50, device="cuda")
+  g = torch.ones((50, 4), device="cuda")
+  t = t.apply_gradients(ids, g, global_step=0, enable_dedup=True)
+  _lib.check(_lib.lib.mono_table_last_phase_ms(h, ms3))
+  assert all(ms3[i] > 0 for i in range(3))
+  assert _lib.lib.mono_table_last_apply_kernel_ms(h, C.byref(ka)) != 0   # 50 ids: no fork
+  ids = torch.cat([torch.arange(5000, device="cuda"),
+                   torch.full((300,), 7, device="cuda", dtype=torch.int64)])
+  t = t.apply_gradients(ids, torch.ones((5300, 4), device="cuda"), global_step=1, enable_dedup=True)
+  _lib.check(_lib.lib.mono_table_last_apply_kernel_ms(h, C.byref(ka)))
+  _lib.check(_lib.lib.mono_table_last_phase_ms(h, ms3))
+  assert 0 < ka.value <= ms3[2]
+  _lib.check(_lib.lib.mono_table_profile(h, 0))
