@@ -273,53 +273,49 @@ __device__ inline int64_t floormod_dev(int64_t a, int64_t b) {
   return r < 0 ? r + b : r;
 }
 
-// Pass 1: per-slot dedup set in HBM (open addressing, 64-bit CAS); every cell remembers the
-// smallest global occurrence index that hit it = the first occurrence. A cell is 16 bytes
-// {int64 key; uint32 first; pad}: key probe and first-occurrence update touch ONE line (as two
-// arrays the insert was bound by random line requests). hkeys / hfirst point into the same
-// array: key of cell c = hkeys[2 c], first = hfirst[4 c].
+// Pass 1: per-slot dedup set in HBM, open addressing over 4-byte cells. A cell does not hold the
+// key but the global index of an occurrence of it (its key is ids[index]), and that index only
+// ever decreases, to the key's FIRST occurrence: claiming an empty cell (one 32-bit CAS) already
+// records the occurrence, so a key seen once costs one atomic (with {key, first} cells it cost a
+// 64-bit CAS plus an atomicMin, and device-scope atomics on random words are the bound here,
+// ~20 G/s); the set is a quarter of the size, and so is the fill that resets it.
 __global__ void __launch_bounds__(256) k_reorder_insert(ReorderArgs a, const SlotMeta* sm,
-                                                        int64_t* hkeys, uint32_t* hfirst,
-                                                        uint32_t* hcell, int phase) {
+                                                        uint32_t* hfirst, uint32_t* hcell,
+                                                        int phase) {
   // Two launches. Phase 0 inserts only the first 1/64 of every slot's occurrences, phase 1 the
   // rest. A hot key (thousands of occurrences) almost surely occurs in that head, so by the time
   // the bulk runs its cell already holds a small index and the guarded atomicMin below is
-  // skipped; in one launch ~10 k concurrent occurrences of one key would all see the initial
-  // value and serialise on a single word (~90 atomics / us).
+  // skipped; in one launch ~10 k concurrent occurrences of one key would all see a large index
+  // and serialise on a single word (~90 atomics / us).
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total;
        g += (int64_t)gridDim.x * blockDim.x) {
     const int m = find_slot_of(sm, a.M, g);
-    const SlotMeta s = sm[m];
-    const bool head = (g - s.base) < ((s.len + 63) >> 6);
+    const int64_t s_base = sm[m].base, s_len = sm[m].len, s_hash_base = sm[m].hash_base;
+    const uint64_t s_mask = sm[m].hash_mask;
+    const int64_t* __restrict__ s_ids = sm[m].ids;
+    const bool head = (g - s_base) < ((s_len + 63) >> 6);
     if (head != (phase == 0)) continue;
-    const int64_t key = s.ids[g - s.base];
-    int64_t cell;
-    if (key == -1) {
-      cell = s.hash_base + (int64_t)s.hash_mask + 1;
-    } else {
-      uint64_t p = mix64((uint64_t)key) & s.hash_mask;
-      for (;;) {
-        int64_t* kp = hkeys + 2 * (s.hash_base + (int64_t)p);
-        int64_t cur = *kp;
-        if (cur == -1) {
-          cur = (int64_t)atomicCAS(reinterpret_cast<unsigned long long*>(kp),
-                                   (unsigned long long)(-1ll), (unsigned long long)key);
-          if (cur == -1) cur = key;
-        }
-        if (cur == key) break;
-        p = (p + 1) & s.hash_mask;
+    const int64_t key = s_ids[g - s_base];
+    uint64_t p = mix64((uint64_t)key) & s_mask;
+    for (;;) {
+      uint32_t* cp = hfirst + (s_hash_base + (int64_t)p);
+      uint32_t cur = *cp;
+      if (cur == 0xFFFFFFFFu) {
+        cur = atomicCAS(cp, 0xFFFFFFFFu, (uint32_t)g);
+        if (cur == 0xFFFFFFFFu) break;  // claimed: the cell says "first seen at g"
       }
-      cell = s.hash_base + (int64_t)p;
+      // the cell belongs to the key of occurrence `cur` (same slot: regions are per slot); a
+      // later atomicMin can only replace cur by another occurrence of that same key
+      if (s_ids[(int64_t)cur - s_base] == key) {
+        // first only decreases: an occurrence that already sees a smaller index has nothing to
+        // add, which spares the hot keys tens of thousands of serialised atomics on one word. A
+        // stale value can only be LARGER than the current one, i.e. cause a redundant atomic.
+        if (cur > (uint32_t)g) atomicMin(cp, (uint32_t)g);
+        break;
+      }
+      p = (p + 1) & s_mask;
     }
-    hcell[g] = (uint32_t)cell;
-    // first only decreases: an occurrence that already sees a smaller index has nothing to add,
-    // which spares the hot keys tens of thousands of serialised atomics on one word. A plain
-    // (cacheable) load: the word shares the line the key probe just fetched, and a stale value
-    // can only be LARGER than the current one, i.e. cause a redundant atomic, never a missed one.
-    // (Device-scope atomics on random words run at ~20 G/s on this part; a load that goes to
-    // memory for the guard costs as much as the atomic it saves.)
-    uint32_t* fp = hfirst + 4 * (size_t)cell;
-    if (*fp > (uint32_t)g) atomicMin(fp, (uint32_t)g);
+    hcell[g] = (uint32_t)(s_hash_base + (int64_t)p);
   }
 }
 
@@ -332,7 +328,7 @@ __global__ void __launch_bounds__(256) k_reorder_keys(ReorderArgs a, const SlotM
        g += (int64_t)gridDim.x * blockDim.x) {
     const int m = find_slot_of(sm, a.M, g);
     uint32_t key = (uint32_t)(a.N * a.M);
-    if (hfirst[4 * (size_t)hcell[g]] == (uint32_t)g) {
+    if (hfirst[hcell[g]] == (uint32_t)g) {
       const int64_t id = sm[m].ids[g - sm[m].base];
       // distribution_ops.py:255-272
       const int shard = a.shard_rule == 1 ? (int)(1 + floormod_dev(id, a.N - 1))
@@ -374,7 +370,7 @@ __global__ void __launch_bounds__(256) k_reorder_emit(ReorderArgs a, const SlotM
     const uint32_t g = sidx[r];
     const SlotMeta& s = sm[key % a.M];
     out_ids[r] = s.ids[(int64_t)g - s.base];
-    hfirst[4 * (size_t)hcell[g]] = (uint32_t)emb_off[r];  // the cell now carries the embedding offset
+    hfirst[hcell[g]] = (uint32_t)emb_off[r];  // the cell now carries the embedding offset
   }
 }
 
@@ -384,7 +380,7 @@ __global__ void __launch_bounds__(256) k_reorder_offsets(ReorderArgs a, const Sl
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total;
        g += (int64_t)gridDim.x * blockDim.x) {
     const int m = find_slot_of(sm, a.M, g);
-    sm[m].out_off[g - sm[m].base] = (int32_t)hfirst[4 * (size_t)hcell[g]];
+    sm[m].out_off[g - sm[m].base] = (int32_t)hfirst[hcell[g]];
   }
 }
 
@@ -408,7 +404,7 @@ __global__ void __launch_bounds__(256) k_shard_keys(ShardArgs a, const SlotMeta*
        g += (int64_t)gridDim.x * blockDim.x) {
     const int m = find_slot_of(sm, a.M, g);
     uint32_t key = (uint32_t)a.n_out;
-    if (!a.unique || hfirst[4 * (size_t)hcell[g]] == (uint32_t)g) {
+    if (!a.unique || hfirst[hcell[g]] == (uint32_t)g) {
       const int64_t id = sm[m].ids[g - sm[m].base];
       key = (uint32_t)a.out_index[m * a.ps_num + shard_of_fid(id, a.ps_num)];
     }
@@ -437,7 +433,7 @@ __global__ void __launch_bounds__(256) k_shard_emit(ShardArgs a, const SlotMeta*
     const int m = find_slot_of(sm, a.M, g);
     fid_list[r] = sm[m].ids[(int64_t)g - sm[m].base];
     const uint32_t idx = (uint32_t)(r - start[key]);
-    if (a.unique) hfirst[4 * (size_t)hcell[g]] = idx;  // the dedup cell now carries the list index
+    if (a.unique) hfirst[hcell[g]] = idx;  // the dedup cell now carries the list index
     else fid_offset[g] = ((uint64_t)key << 32) | idx;
   }
 }
@@ -451,7 +447,7 @@ __global__ void __launch_bounds__(256) k_shard_offsets(ShardArgs a, const SlotMe
     const int m = find_slot_of(sm, a.M, g);
     const int64_t id = sm[m].ids[g - sm[m].base];
     const uint32_t key = (uint32_t)a.out_index[m * a.ps_num + shard_of_fid(id, a.ps_num)];
-    fid_offset[g] = ((uint64_t)key << 32) | hfirst[4 * (size_t)hcell[g]];
+    fid_offset[g] = ((uint64_t)key << 32) | hfirst[hcell[g]];
   }
 }
 
@@ -700,8 +696,8 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   size_t bytes = 256 + sizeof(SlotMeta) * M + 64;
   const size_t off_meta = 256;
   const size_t off_hkeys = (off_meta + sizeof(SlotMeta) * M + 63) & ~(size_t)63;
-  const size_t off_hfirst = off_hkeys + 8;  // interleaved 16-byte cells
-  const size_t off_hcell = off_hkeys + c_al * 16;
+  const size_t off_hfirst = off_hkeys;  // 4-byte cells
+  const size_t off_hcell = off_hkeys + c_al * 4;
   const size_t off_skey = off_hcell + t_al * 4;
   const size_t off_sidx = off_skey + t_al * 4;
   const size_t off_skey2 = off_sidx + t_al * 4;
@@ -713,7 +709,6 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   MONO_TRY(g_ws.ensure(bytes));
   char* base = (char*)g_ws.ptr;
   SlotMeta* d_sm = (SlotMeta*)(base + off_meta);
-  int64_t* hkeys = (int64_t*)(base + off_hkeys);
   uint32_t* hfirst = (uint32_t*)(base + off_hfirst);
   uint32_t* hcell = (uint32_t*)(base + off_hcell);
   uint32_t* skey = (uint32_t*)(base + off_skey);
@@ -724,12 +719,12 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   int32_t* scan = (int32_t*)(base + off_scan);
   int32_t* hist = (int32_t*)(base + off_hist);
   MONO_HIP(hipMemcpyAsync(d_sm, sm.data(), sizeof(SlotMeta) * M, hipMemcpyHostToDevice, st));
-  MONO_HIP(hipMemsetAsync(hkeys, 0xFF, c_al * 16, st));
+  MONO_HIP(hipMemsetAsync(hfirst, 0xFF, c_al * 4, st));
   MONO_HIP(hipMemsetAsync(hist, 0, hist_al * 4, st));
   ReorderArgs a{M, N, shard_rule, total};
   const dim3 grid(grid_for(total, 256)), blk(256);
-  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hkeys, hfirst, hcell, 0);
-  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hkeys, hfirst, hcell, 1);
+  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hfirst, hcell, 0);
+  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hfirst, hcell, 1);
   hipLaunchKernelGGL(k_reorder_keys, grid, blk, 0, st, a, d_sm, hfirst, hcell, skey, sidx);
   MONO_HIP(hipGetLastError());
   MONO_TRY(sort_pairs(skey, skey2, sidx, sidx2, (size_t)total,
@@ -794,8 +789,8 @@ int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* 
   const size_t off_rm = (off_sm + sizeof(SlotMeta) * M + 63) & ~(size_t)63;
   const size_t off_oi = (off_rm + sizeof(RunMeta) * M + 63) & ~(size_t)63;
   const size_t off_hkeys = (off_oi + (size_t)M * ps_num * 4 + 63) & ~(size_t)63;
-  const size_t off_hfirst = off_hkeys + 8;  // interleaved 16-byte cells
-  const size_t off_hcell = off_hkeys + c_al * 16;
+  const size_t off_hfirst = off_hkeys;  // 4-byte cells
+  const size_t off_hcell = off_hkeys + c_al * 4;
   const size_t off_skey = off_hcell + (unique ? t_al * 4 : 0);
   const size_t off_skey2 = off_skey + t_al * 4;
   const size_t off_sidx2 = off_skey2 + t_al * 4;
@@ -806,7 +801,6 @@ int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* 
   SlotMeta* d_sm = (SlotMeta*)(base + off_sm);
   RunMeta* d_rm = (RunMeta*)(base + off_rm);
   int32_t* d_oi = (int32_t*)(base + off_oi);
-  int64_t* hkeys = (int64_t*)(base + off_hkeys);
   uint32_t* hfirst = (uint32_t*)(base + off_hfirst);
   uint32_t* hcell = (uint32_t*)(base + off_hcell);
   uint32_t* skey = (uint32_t*)(base + off_skey);
@@ -829,10 +823,10 @@ int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* 
   const dim3 grid(grid_for(total, 256));
   ShardArgs a{M, ps_num, n_out, unique ? 1 : 0, total, d_oi};
   if (unique) {
-    MONO_HIP(hipMemsetAsync(hkeys, 0xFF, c_al * 16, st));
+    MONO_HIP(hipMemsetAsync(hfirst, 0xFF, c_al * 4, st));
     ReorderArgs ra{M, ps_num, 0, total};
-    hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hkeys, hfirst, hcell, 0);
-    hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hkeys, hfirst, hcell, 1);
+    hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hfirst, hcell, 0);
+    hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hfirst, hcell, 1);
   }
   hipLaunchKernelGGL(k_shard_keys, grid, blk, 0, st, a, d_sm, hfirst, hcell, skey);
   MONO_HIP(hipGetLastError());

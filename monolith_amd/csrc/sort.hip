@@ -575,28 +575,36 @@ extern "C" int mono_debug_sort_error(void) {
 
 // Test / measurement hook: sort n pairs on the low end_bit key bits (vin NULL = identity values),
 // reps times, average milliseconds per sort (HIP events on the stream) in *avg_ms.
-extern "C" int mono_debug_sort_pairs(const uint32_t* kin, const uint32_t* vin, int64_t n,
-                                     int end_bit, uint32_t* kout, uint32_t* vout, int reps,
-                                     float* avg_ms, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  MONO_REQUIRE(n >= 0 && reps >= 1, "mono_debug_sort_pairs: bad arguments");
-  const size_t bytes = mono::sort_pairs_tmp_bytes((size_t)n, end_bit);
-  void* tmp = nullptr;
-  MONO_HIP(hipMalloc(&tmp, bytes));
-  hipEvent_t e0, e1;
-  MONO_HIP(hipEventCreate(&e0));
-  MONO_HIP(hipEventCreate(&e1));
-  int rc = 0;
+static int debug_sort_run(const uint32_t* kin, const uint32_t* vin, int64_t n, int end_bit,
+                          uint32_t* kout, uint32_t* vout, int reps, float* avg_ms, hipStream_t st,
+                          void* tmp, size_t bytes, hipEvent_t e0, hipEvent_t e1) {
   MONO_HIP(hipEventRecord(e0, st));
-  for (int r = 0; r < reps && rc == 0; ++r)
-    rc = mono::sort_pairs_u32(kin, kout, vin, vout, (size_t)n, end_bit, tmp, bytes, st);
+  for (int r = 0; r < reps; ++r)
+    MONO_TRY(mono::sort_pairs_u32(kin, kout, vin, vout, (size_t)n, end_bit, tmp, bytes, st));
   MONO_HIP(hipEventRecord(e1, st));
   MONO_HIP(hipStreamSynchronize(st));
   float ms = 0.f;
   MONO_HIP(hipEventElapsedTime(&ms, e0, e1));
   if (avg_ms) *avg_ms = ms / (float)reps;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  MONO_HIP(hipFree(tmp));
+  return 0;
+}
+
+extern "C" int mono_debug_sort_pairs(const uint32_t* kin, const uint32_t* vin, int64_t n,
+                                     int end_bit, uint32_t* kout, uint32_t* vout, int reps,
+                                     float* avg_ms, void* stream) {
+  MONO_REQUIRE(n >= 0 && reps >= 1, "mono_debug_sort_pairs: bad arguments");
+  const size_t bytes = mono::sort_pairs_tmp_bytes((size_t)n, end_bit);
+  void* tmp = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = 0;
+  if (hipMalloc(&tmp, bytes) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+      hipEventCreate(&e1) != hipSuccess)
+    rc = mono::fail("mono_debug_sort_pairs: cannot allocate %zu bytes of scratch / events", bytes);
+  else
+    rc = debug_sort_run(kin, vin, n, end_bit, kout, vout, reps, avg_ms, (hipStream_t)stream, tmp,
+                        bytes, e0, e1);
+  if (e0) (void)hipEventDestroy(e0);  // whatever happened above, nothing stays allocated
+  if (e1) (void)hipEventDestroy(e1);
+  if (tmp) (void)hipFree(tmp);
   return rc;
 }
