@@ -110,10 +110,10 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
     # The per-(shard, slot) counts travel first (fixed size, K per peer): their row sums are the
     # FID counts every peer is about to send, so the FID exchange needs no size message of its
     # own (one collective and one host synchronisation fewer per step than hvd.alltoall's).
-    shard_sizes_h = [int(x) for x in torch.as_tensor(shard_sizes).tolist()]
+    shard_sizes_h = torch.as_tensor(shard_sizes).tolist()
     sss = torch.as_tensor(sharded_slot_sizes, dtype=torch.int32)
     if _world(self._group)[1] == 1 and not _forced_collective():
-      id_size_flat_h = sss.cpu()
+      id_size_flat_h = sss if not sss.is_cuda else sss.cpu()
     else:
       id_size_flat_t, _ = alltoall(sss.to(all_fids.device), [slot_num] * self._shard_num,
                                    recv_splits=[slot_num] * self._shard_num, group=self._group)

@@ -437,26 +437,30 @@ def fused_lookup(tables: List, ids, fused_slot_size, num_of_shards: int):
   res, hs = _handles(tables)
   K, N = len(res), int(num_of_shards)
   ids = _ids(ids)
-  fss = torch.as_tensor(fused_slot_size, dtype=torch.int32).cpu().contiguous()
-  if fss.numel() != K * N:
+  # The caller is usually waiting on a size it just read back, so the time to the first launch
+  # is GPU idle time: host metadata stays in numpy (a torch CPU op costs several microseconds),
+  # and the output length = sum over (shard, table) cells of ids * dim is computed here so that
+  # the kernels go out with ONE call.
+  if isinstance(fused_slot_size, torch.Tensor):
+    fused_slot_size = fused_slot_size.cpu().numpy()
+  fss = np.ascontiguousarray(fused_slot_size, dtype=np.int32).reshape(-1)
+  if fss.size != K * N:
     raise _lib.MonolithHipError("len(fused_slot_size) / num_of_shards != len(table_handles)")
-  if int(fss.sum()) != ids.numel():
+  cells = fss.tolist()
+  if sum(cells) != ids.numel():
     raise _lib.MonolithHipError("sum(fused_slot_size) != len(ids)")
-  splits = torch.zeros(N, dtype=torch.int32)
-  id_off = torch.zeros(K * N, dtype=torch.int32)
-  emb_off = torch.zeros(K * N, dtype=torch.int32)
-  emb_sizes = torch.zeros(K * N, dtype=torch.int32)
-  args = (hs, C.c_int(K), _lib.vp(ids), C.c_void_p(fss.data_ptr()), C.c_int(N))
-  meta = (C.c_void_p(splits.data_ptr()), C.c_void_p(id_off.data_ptr()),
-          C.c_void_p(emb_off.data_ptr()), C.c_void_p(emb_sizes.data_ptr()))
-  # output length = sum over (shard, table) cells of ids * dim: known on the host, so the kernels
-  # go out with ONE call (the caller is often waiting on a size it just read back: the time to
-  # the first launch is GPU idle time)
+  meta_buf = np.zeros(N + 3 * K * N, np.int32)
+  splits, id_off = meta_buf[:N], meta_buf[N:N + K * N]
+  emb_off, emb_sizes = meta_buf[N + K * N:N + 2 * K * N], meta_buf[N + 2 * K * N:]
   dims = [r.dim for r in res]
-  total = sum(int(c) * dims[i % K] for i, c in enumerate(fss.tolist()))
+  total = sum(c * dims[i % K] for i, c in enumerate(cells))
   emb = torch.empty(total, dtype=torch.float32, device=ids.device)
-  _lib.check(_lib.lib.mono_tables_fused_lookup(*args, _lib.vp(emb), *meta, _lib.stream_ptr()))
-  return emb, splits, id_off, emb_off, emb_sizes
+  _lib.check(_lib.lib.mono_tables_fused_lookup(
+      hs, C.c_int(K), _lib.vp(ids), C.c_void_p(fss.ctypes.data), C.c_int(N), _lib.vp(emb),
+      C.c_void_p(splits.ctypes.data), C.c_void_p(id_off.ctypes.data),
+      C.c_void_p(emb_off.ctypes.data), C.c_void_p(emb_sizes.ctypes.data), _lib.stream_ptr()))
+  return (emb, torch.from_numpy(splits), torch.from_numpy(id_off), torch.from_numpy(emb_off),
+          torch.from_numpy(emb_sizes))
 
 
 def fused_apply_gradient(tables: List, ids, fused_slot_size, id_grads, id_offsets, grad_offsets,
