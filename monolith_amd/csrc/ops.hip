@@ -361,8 +361,9 @@ __global__ void __launch_bounds__(256) k_reorder_hist(ReorderArgs a, const uint3
 
 __global__ void __launch_bounds__(256) k_reorder_emit(ReorderArgs a, const SlotMeta* sm,
                                                       const uint32_t* skey, const uint32_t* sidx,
-                                                      const int32_t* emb_off, const uint32_t* hcell,
-                                                      uint32_t* hfirst, int64_t* out_ids) {
+                                                      const int32_t* emb_off, int uniform_dim,
+                                                      const uint32_t* hcell, uint32_t* hfirst,
+                                                      int64_t* out_ids) {
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.total;
        r += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t key = skey[r];
@@ -370,7 +371,10 @@ __global__ void __launch_bounds__(256) k_reorder_emit(ReorderArgs a, const SlotM
     const uint32_t g = sidx[r];
     const SlotMeta& s = sm[key % a.M];
     out_ids[r] = s.ids[(int64_t)g - s.base];
-    hfirst[hcell[g]] = (uint32_t)emb_off[r];  // the cell now carries the embedding offset
+    // the cell now carries the embedding offset: the exclusive scan of the dims, or, when every
+    // slot has the same dim, simply rank * dim (unique ids sort to the front, the rest to a
+    // sentinel key at the end)
+    hfirst[hcell[g]] = emb_off ? (uint32_t)emb_off[r] : (uint32_t)r * (uint32_t)uniform_dim;
   }
 }
 
@@ -729,12 +733,18 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   MONO_HIP(hipGetLastError());
   MONO_TRY(sort_pairs(skey, skey2, sidx, sidx2, (size_t)total,
                                     bits_for_u((uint64_t)N * M), st));
-  hipLaunchKernelGGL(k_reorder_dims, grid, blk, 0, st, a, d_sm, skey2, dims);
+  bool uniform = true;  // one dim for every slot: offsets need no scan
+  for (int m = 1; m < M; ++m) uniform = uniform && h_dims[m] == h_dims[0];
+  uniform = uniform && total * (int64_t)h_dims[0] < (int64_t)0x7FFFFFF0;
   hipLaunchKernelGGL(k_reorder_hist, dim3(grid_for((int64_t)N * M, 256)), blk, 0, st, a, skey2, hist);
-  MONO_HIP(hipGetLastError());
-  MONO_TRY(exclusive_scan_i32(dims, scan, (size_t)total, st));
-  hipLaunchKernelGGL(k_reorder_emit, grid, blk, 0, st, a, d_sm, skey2, sidx2, scan, hcell, hfirst,
-                     out_ids);
+  if (!uniform) {
+    hipLaunchKernelGGL(k_reorder_dims, grid, blk, 0, st, a, d_sm, skey2, dims);
+    MONO_HIP(hipGetLastError());
+    MONO_TRY(exclusive_scan_i32(dims, scan, (size_t)total, st));
+  }
+  hipLaunchKernelGGL(k_reorder_emit, grid, blk, 0, st, a, d_sm, skey2, sidx2,
+                     uniform ? (const int32_t*)nullptr : scan, uniform ? h_dims[0] : 0, hcell,
+                     hfirst, out_ids);
   hipLaunchKernelGGL(k_reorder_offsets, grid, blk, 0, st, a, d_sm, hfirst, hcell);
   MONO_HIP(hipGetLastError());
   MONO_HIP(hipMemcpyAsync(h_sharded_slot_sizes, hist, (size_t)N * M * 4, hipMemcpyDeviceToHost, st));

@@ -51,14 +51,15 @@ def test_fused_reorder_random_vs_oracle(ops, monkeypatch, n_shards, rank0):
   rule = 1 if (n_shards > 4 and rank0 == "1") else 0
   rng = np.random.Generator(np.random.PCG64(n_shards * 7 + int(rank0)))
   lens = [0, 1, 37, 5000, 20000, 3]
-  dims = [4, 1, 16, 8, 3, 2]
   inputs = [(rng.integers(-50, max(60, l // 3), l) * 1000003).astype(np.int64) for l in lens]
-  o, s, ss, of = d_ops.fused_reorder_by_indices([T(x, torch.int64) for x in inputs], n_shards, dims)
-  eo, es, ess, eof = cpu.fused_reorder_by_indices(inputs, n_shards, dims, shard_rule=rule)
-  assert np.array_equal(o.cpu().numpy(), eo)
-  assert np.array_equal(s.numpy(), es) and np.array_equal(ss.numpy(), ess)
-  for a, b in zip(of, eof):
-    assert np.array_equal(a.cpu().numpy().reshape(-1), b)
+  # mixed dims (offsets = exclusive scan of the dims) and one dim for all (offsets = rank * dim)
+  for dims in ([4, 1, 16, 8, 3, 2], [16] * 6):
+    o, s, ss, of = d_ops.fused_reorder_by_indices([T(x, torch.int64) for x in inputs], n_shards, dims)
+    eo, es, ess, eof = cpu.fused_reorder_by_indices(inputs, n_shards, dims, shard_rule=rule)
+    assert np.array_equal(o.cpu().numpy(), eo)
+    assert np.array_equal(s.numpy(), es) and np.array_equal(ss.numpy(), ess)
+    for a, b in zip(of, eof):
+      assert np.array_equal(a.cpu().numpy().reshape(-1), b)
 
 
 def test_fused_gather_and_gradient(ops):
