@@ -720,8 +720,11 @@ __device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t e
 // B3/B4: bridge :156-313, cuckoo_embedding_hash_table.cc:174-216, entry_accessor.cc:149-171.
 // 8 waves / SIMD (64 VGPRs, a 36-byte spill): the kernel is bound by memory latency x resident
 // sub-groups, and the extra wave is worth more than the spill costs (7.83 -> 8.01 G).
-template <int V, int OPTK>
+// MODE_T >= 0 fixes the mode at compile time (the dedup instantiation of the headline step then
+// carries none of the other walks: fewer live registers at 8 waves / SIMD); -1 reads mode.
+template <int V, int OPTK, int MODE_T = -1>
 __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
+  const int mode = MODE_T >= 0 ? MODE_T : a.mode;
   const int sub = lane_sub(), gshift = lane_gshift();
   int64_t j = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
   if (j >= a.n) return;
@@ -771,7 +774,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
         int thr = filter_threshold(a.filt, key);
         if (thr > 0) {
           uint32_t c = 0;
-          if (a.mode == MODE_OPT_DEDUP) {
+          if (mode == MODE_OPT_DEDUP) {
             // one add(fid, k); admitted iff old count >= threshold
             if (sub == 0) c = filter_add(a.filt, (uint64_t)key, (uint32_t)min((int64_t)15, k));
             c = __shfl(c, 0, 8);
@@ -804,13 +807,13 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
   }
 
   if (end - first > kLongSeg && D <= kLongMaxDim && !t.serving && !t.any_sr &&
-      (a.mode == MODE_ASSIGN_ADD || a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP)) {
+      (mode == MODE_ASSIGN_ADD || mode == MODE_OPT_SEQ || mode == MODE_OPT_DEDUP)) {
     if (sub == 0) enqueue_long(a, first, end, key, slot, fresh ? 1u : 0u);
     return;
   }
 
   float* row = t.rows + (uint64_t)slot * R;
-  if (a.mode == MODE_IMPORT) {  // full-row restore: last occurrence wins
+  if (mode == MODE_IMPORT) {  // full-row restore: last occurrence wins
     uint32_t src_i = a.sidx[end - 1];
     if (t.serving) {  // Restore = Encode(dump.num) (entry_accessor.cc:89-94); R == D here
       for (int e = sub; e < R; e += 8) {
@@ -859,7 +862,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       for (int q = 0; q < V; ++q)
         if (t.seg[segi[q]].sr_post) ox[q].gstep = 0;
     }
-    const bool need_state = a.mode >= MODE_OPT_SEQ;
+    const bool need_state = mode >= MODE_OPT_SEQ;
     if (fresh) {
 #pragma unroll
       for (int q = 0; q < V; ++q) {
@@ -886,13 +889,13 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       for (int q = 0; q < V; ++q) optx_load(t, t.seg[segi[q]], row, e0 + q, fresh, key, ox[q]);
     }
     // --- walk the occurrences in input order
-    if (a.mode == MODE_ASSIGN) {
+    if (mode == MODE_ASSIGN) {
       vload<V>(w, a.src + (uint64_t)a.sidx[end - 1] * D + e0);
       if (OPTK == OPTK_MULTI && t.serving) {
 #pragma unroll
         for (int q = 0; q < V; ++q) w[q] = comp_q(t.seg[segi[q]], w[q]);
       }
-    } else if (a.mode == MODE_ASSIGN_ADD) {
+    } else if (mode == MODE_ASSIGN_ADD) {
       int64_t p = first;
       if (!(OPTK == OPTK_MULTI && t.serving)) {
         // 4 independent row loads in flight, adds stay in input order (a walk with one load at a
@@ -917,7 +920,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
           for (int q = 0; q < V; ++q) w[q] = comp_q(t.seg[segi[q]], w[q]);
         }
       }
-    } else if (a.mode == MODE_OPT_SEQ) {
+    } else if (mode == MODE_OPT_SEQ) {
       for (int64_t p = first; p < end; ++p) {
         float g[V];
         vload<V>(g, a.src + (uint64_t)a.sidx[p] * D + e0);
@@ -1506,7 +1509,11 @@ static void launch_lookup(const Table* t, const int64_t* ids, int64_t n, float* 
 
 template <int V, int OPTK>
 static void launch_apply_vo(const Table* t, const ApplyArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL((k_apply<V, OPTK>), dim3((unsigned)((a.n + 31) / 32)), dim3(256), 0, st, t->d, a);
+  const dim3 grid((unsigned)((a.n + 31) / 32));
+  if (a.mode == MODE_OPT_DEDUP && !a.from_keys)
+    hipLaunchKernelGGL((k_apply<V, OPTK, MODE_OPT_DEDUP>), grid, dim3(256), 0, st, t->d, a);
+  else
+    hipLaunchKernelGGL((k_apply<V, OPTK>), grid, dim3(256), 0, st, t->d, a);
 }
 template <int V>
 static void launch_apply_v(const Table* t, const ApplyArgs& a, hipStream_t st) {
