@@ -921,18 +921,35 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
         }
       }
     } else if (mode == MODE_OPT_SEQ) {
-      for (int64_t p = first; p < end; ++p) {
-        float g[V];
-        vload<V>(g, a.src + (uint64_t)a.sidx[p] * D + e0);
+      auto step_one = [&](const float(&g)[V], uint32_t pos) {  // one Optimize call of this id
 #pragma unroll
         for (int q = 0; q < V; ++q) {
           const SegDev& sg = t.seg[segi[q]];
           if (OPTK == OPTK_MULTI && t.any_sr && sg.sr_pre >= 0)
-            w[q] = stochastic_round(w[q], sr_uniform(t.seed, a.global_step, a.sidx[p], e0 + q, sg.sr_pre));
+            w[q] = stochastic_round(w[q], sr_uniform(t.seed, a.global_step, pos, e0 + q, sg.sr_pre));
           opt_step(kind[q], sg, a.lr[segi[q]], g[q], w[q], s0[q], s1[q], ox[q]);
           if (OPTK == OPTK_MULTI && t.any_sr && sg.sr_post)
-            w[q] = stochastic_round(w[q], sr_uniform(t.seed, a.global_step, a.sidx[p], e0 + q, segi[q]));
+            w[q] = stochastic_round(w[q], sr_uniform(t.seed, a.global_step, pos, e0 + q, segi[q]));
         }
+      };
+      int64_t p = first;
+      for (; p + 4 <= end; p += 4) {  // the steps depend on each other, the row loads do not
+        const uint32_t i0 = a.sidx[p], i1 = a.sidx[p + 1], i2 = a.sidx[p + 2], i3 = a.sidx[p + 3];
+        float g0[V], g1[V], g2[V], g3[V];
+        vload<V>(g0, a.src + (uint64_t)i0 * D + e0);
+        vload<V>(g1, a.src + (uint64_t)i1 * D + e0);
+        vload<V>(g2, a.src + (uint64_t)i2 * D + e0);
+        vload<V>(g3, a.src + (uint64_t)i3 * D + e0);
+        step_one(g0, i0);
+        step_one(g1, i1);
+        step_one(g2, i2);
+        step_one(g3, i3);
+      }
+      for (; p < end; ++p) {
+        float g[V];
+        const uint32_t i0 = a.sidx[p];
+        vload<V>(g, a.src + (uint64_t)i0 * D + e0);
+        step_one(g, i0);
       }
     } else {  // MODE_OPT_DEDUP: in-order sum (bridge :251-266), then one step
       float acc[V];
