@@ -725,12 +725,16 @@ __device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t e
 template <int V, int OPTK, int MODE_T = -1>
 __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
   const int mode = MODE_T >= 0 ? MODE_T : a.mode;
+  // the fixed-mode instantiation is launched on the no-filter path only: slots are resolved and
+  // k_classify has compacted the segment heads
+  const bool from_keys = MODE_T >= 0 ? false : (a.from_keys != 0);
+  const bool has_heads = MODE_T >= 0 ? true : (a.heads != nullptr);
   const int sub = lane_sub(), gshift = lane_gshift();
   int64_t j = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
   if (j >= a.n) return;
   const int D = t.dim, R = t.row_floats;
   uint4 hd = make_uint4(0u, 0u, 0u, 0u);
-  if (a.heads) {  // compacted segment heads (k_classify): every sub-group has work
+  if (has_heads) {  // compacted segment heads (k_classify): every sub-group has work
     if (j >= (int64_t)*a.nheads) return;
     hd = a.heads[j];
     j = hd.x;
@@ -742,11 +746,11 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
   bool fresh = false; // row claimed here and not yet initialised in memory
   int64_t key = 0;
   uint32_t idx0 = 0;  // occurrence index of sorted position j
-  if (!a.from_keys) {
+  if (!from_keys) {
     const uint32_t* sk = static_cast<const uint32_t*>(a.skeys);
     // four independent loads up front: the common single-occurrence segment then needs only
     // two dependent memory levels (sorted arrays -> row + gradient)
-    if (a.heads) {  // slot and first index ride in the head record: one memory level less
+    if (has_heads) {  // slot and first index ride in the head record: one memory level less
       slot = hd.z;
       idx0 = hd.w;
       end = j + hd.y;
