@@ -349,7 +349,7 @@ def main():
       "radix_sort(slot,idx)": (sort_ms, 0),
       "apply phase": (apply_ms, n * 4 * D + uniq * n * (2 * (4 * D + 4 * D) + 4)),
   }
-  if kapply_ms == kapply_ms:  # the kernel alone: what rocprofv3 reports as mono::k_apply<2, 1>
+  if kapply_ms == kapply_ms:  # the kernel alone: what rocprofv3 reports as mono::k_apply<2, 1, 3>
     kern["k_apply"] = (kapply_ms, (n - n_long) * 4 * D + (uniq * n - u_long) * (2 * (4 * D + 4 * D) + 4))
   else:
     kern["k_apply"] = kern["apply phase"]
@@ -360,16 +360,16 @@ def main():
   # separate rocprofv3 --pmc runs of this same command; calibration note in the summary file)
   traffic, traffic_src = None, None
   try:
-    with open(os.path.join(ROOT, "profiles", "r01_h_pmc_summary.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r01_i_pmc_summary.json")) as f:
       pmc = json.load(f)["kernels"]
     members = {"k_lookup": ["mono::k_lookup<4>"], "k_claim_pending": ["mono::k_claim_pending"],
-               "k_apply": ["mono::k_apply<2, 1>"] if kapply_ms == kapply_ms else
-                          ["mono::k_classify", "mono::k_apply<2, 1>", "mono::k_apply_long<1, 3>",
+               "k_apply": ["mono::k_apply<2, 1, 3>"] if kapply_ms == kapply_ms else
+                          ["mono::k_classify", "mono::k_apply<2, 1, 3>", "mono::k_apply_long<1, 3>",
                            "mono::k_combine<1>"]}[dom]
     if args.batch == 65536 and args.rows == 1e8 and args.skew == 3.0:
       traffic = sum((pmc[m]["FETCH_SIZE_KB_last_launch"] + pmc[m]["WRITE_SIZE_KB_last_launch"]) *
                     1024.0 for m in members)
-      traffic_src = "profiles/r01_h_pmc_summary.json (" + " + ".join(members) + ")"
+      traffic_src = "profiles/r01_i_pmc_summary.json (" + " + ".join(members) + ")"
   except (OSError, KeyError, ValueError):
     pass
 
