@@ -1531,8 +1531,14 @@ static void launch_lookup(const Table* t, const int64_t* ids, int64_t n, float* 
 template <int V, int OPTK>
 static void launch_apply_vo(const Table* t, const ApplyArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)((a.n + 31) / 32));
-  if (a.mode == MODE_OPT_DEDUP && !a.from_keys)
+  // no-filter path (slots resolved, heads compacted): the walking modes as instantiations of
+  // their own; everything else (filter path, assign, import) through the run-time kernel
+  if (!a.from_keys && a.heads && a.mode == MODE_OPT_DEDUP)
     hipLaunchKernelGGL((k_apply<V, OPTK, MODE_OPT_DEDUP>), grid, dim3(256), 0, st, t->d, a);
+  else if (!a.from_keys && a.heads && a.mode == MODE_OPT_SEQ)
+    hipLaunchKernelGGL((k_apply<V, OPTK, MODE_OPT_SEQ>), grid, dim3(256), 0, st, t->d, a);
+  else if (!a.from_keys && a.heads && a.mode == MODE_ASSIGN_ADD)
+    hipLaunchKernelGGL((k_apply<V, OPTK, MODE_ASSIGN_ADD>), grid, dim3(256), 0, st, t->d, a);
   else
     hipLaunchKernelGGL((k_apply<V, OPTK>), grid, dim3(256), 0, st, t->d, a);
 }
