@@ -503,7 +503,10 @@ struct SplitSeg {
   uint32_t slot, fresh, pbase, nparts;
 };
 constexpr uint32_t kNoPart = 0xFFFFFFFFu;
-constexpr int kLongSeg = 96;       // occurrences above which a segment goes to k_apply_long
+#ifndef MONO_LONG_SEG
+#define MONO_LONG_SEG 96
+#endif
+constexpr int kLongSeg = MONO_LONG_SEG;       // occurrences above which a segment goes to k_apply_long
 // A key with more than kChunk occurrences in one batch is summed in near-equal chunks of at most
 // kChunk occurrences (each chunk in input order, by its own workgroup); k_combine then adds the
 // chunk sums in chunk order. This is the one place the summation order differs from the
