@@ -35,7 +35,8 @@ struct KeySet {
   uint64_t slots = 0;
   int64_t* keys = nullptr;
   uint32_t* mark = nullptr;
-  uint32_t* ctl = nullptr;  // [0] min-flag (holds EMPTY key), [1] overflow position, [2] steal cursor
+  uint32_t* ctl = nullptr;  // [0] min-flag (holds EMPTY key), [1] overflow position, [2] steal cursor,
+                            // [3] error: an insert found no cell (cannot happen, see round_max)
   int64_t size = 0;         // host copy: keys in the set (incl. the flagged EMPTY key)
   bool has_empty_key = false;
   Workspace ws;
@@ -54,15 +55,23 @@ __global__ void __launch_bounds__(256) k_ks_insert(int64_t* keys, uint32_t* mark
       continue;
     }
     uint64_t p = mix64((uint64_t)key) & mask;
-    for (;;) {
+    // The host hands a round at most (cells - keys held - 1) positions, so an empty cell always
+    // exists; the probe is bounded all the same: a full table raises ctl[3] instead of spinning.
+    bool placed = false;
+    for (uint64_t step = 0; step <= mask; ++step) {
       int64_t cur = keys[p];
       if (cur == kKsEmpty) {
         cur = (int64_t)atomicCAS(reinterpret_cast<unsigned long long*>(keys + p),
                                  (unsigned long long)kKsEmpty, (unsigned long long)key);
         if (cur == kKsEmpty) cur = key;
       }
-      if (cur == key) break;
-      p = (p + 1) & mask;  // load <= 1/2 and every wave reaches an empty cell or its key
+      if (cur == key) { placed = true; break; }
+      p = (p + 1) & mask;
+    }
+    if (!placed) {
+      cell_of[g] = kKsNone;
+      atomicExch(&ctl[3], 1u);
+      continue;
     }
     cell_of[g] = (uint32_t)p;
     // keys present before this batch keep PRE; new ones collect their first position
@@ -218,34 +227,44 @@ int mono_keyset_insert(void* set, const int64_t* ids, int64_t n, int64_t* h_drop
   void* tmp = base + off_tmp;
   int64_t lo = 0;
   const dim3 blk(256);
-  // every round either finishes or drops the set and restarts behind the overflow position, so
-  // the loop runs at most n / capacity + 1 times
+  // A round inserts every distinct key of its positions BEFORE the overflow position is known, so
+  // it takes at most round_max positions: the set holds <= capacity + 1 keys when a round starts
+  // (it is dropped as soon as it holds more) and has >= 2 * (capacity + 2) cells, hence at least
+  // one cell stays empty and every probe ends. Every round either commits its positions or drops
+  // the set and restarts at the overflow position (which then commits): <= 2 * n / round_max + 2
+  // rounds.
+  const int64_t round_max = (int64_t)s->slots - (s->capacity + 2) - 1;
   for (;;) {
-    const int64_t m = n - lo;
+    const int64_t hi = std::min(n, lo + round_max);
+    const int64_t m = hi - lo;
     const dim3 grid(grid_for(m, 256));
-    const uint32_t ctl0[3] = {kKsNone, kKsNone, 0};
+    const uint32_t ctl0[4] = {kKsNone, kKsNone, 0, 0};
     MONO_HIP(hipMemcpyAsync(s->ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_ks_insert, grid, blk, 0, st, s->keys, s->mark, s->slots - 1, ids, lo, n,
+    hipLaunchKernelGGL(k_ks_insert, grid, blk, 0, st, s->keys, s->mark, s->slots - 1, ids, lo, hi,
                        cell_of, s->ctl);
-    hipLaunchKernelGGL(k_ks_flags, grid, blk, 0, st, s->mark, cell_of, s->ctl, lo, n,
+    hipLaunchKernelGGL(k_ks_flags, grid, blk, 0, st, s->mark, cell_of, s->ctl, lo, hi,
                        (int)s->has_empty_key, flag);
     MONO_HIP(hipGetLastError());
     MONO_HIP(rocprim::exclusive_scan(tmp, scan_tmp, flag, excl, 0, (size_t)m,
                                      rocprim::plus<int32_t>(), st));
-    hipLaunchKernelGGL(k_ks_overflow, grid, blk, 0, st, excl, lo, n, s->size, s->capacity, s->ctl);
+    hipLaunchKernelGGL(k_ks_overflow, grid, blk, 0, st, excl, lo, hi, s->size, s->capacity, s->ctl);
     MONO_HIP(hipGetLastError());
-    uint32_t h_ctl[2];
+    uint32_t h_ctl[4];
     int32_t last[2];
     MONO_HIP(hipMemcpyAsync(h_ctl, s->ctl, sizeof(h_ctl), hipMemcpyDeviceToHost, st));
     MONO_HIP(hipMemcpyAsync(&last[0], excl + (m - 1), 4, hipMemcpyDeviceToHost, st));
     MONO_HIP(hipMemcpyAsync(&last[1], flag + (m - 1), 4, hipMemcpyDeviceToHost, st));
     MONO_HIP(hipStreamSynchronize(st));
-    if (h_ctl[1] == kKsNone) {  // no overflow inside the batch: commit
-      hipLaunchKernelGGL(k_ks_commit, grid, blk, 0, st, s->mark, cell_of, lo, n);
+    MONO_REQUIRE(h_ctl[3] == 0, "mono_keyset_insert: the set's %llu cells are full (internal error)",
+                 (unsigned long long)s->slots);
+    if (h_ctl[1] == kKsNone) {  // no overflow inside this round: commit it
+      hipLaunchKernelGGL(k_ks_commit, grid, blk, 0, st, s->mark, cell_of, lo, hi);
       MONO_HIP(hipGetLastError());
       s->size += (int64_t)last[0] + last[1];
       if (h_ctl[0] != kKsNone) s->has_empty_key = true;
-      return 0;
+      if (hi == n) return 0;
+      lo = hi;
+      continue;
     }
     // the set is dropped right before position p (hopscotch_hash_set.cc:113-122)
     const int64_t p = (int64_t)h_ctl[1];

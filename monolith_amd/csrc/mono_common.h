@@ -83,6 +83,11 @@ size_t sort_pairs_tmp_bytes(size_t n, int end_bit);
 int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
                    size_t n, int end_bit, void* tmp, size_t tmp_bytes, hipStream_t st);
 
+// The fused passes' sticky error word on the current device (never allocates; nullptr only if
+// the device cannot be queried) and the message for a non-zero value read back by the caller.
+uint32_t* sort_error_word();
+int sort_error_report(uint32_t h_word);
+
 // table.hip: out[skeys[p] .. + D) += src[sidx[p]] over the sorted positions p, every segment summed
 // left to right (segments longer than 4096 in ordered chunks). `aligned4`: every key is a
 // multiple of 4 floats and `out` is 16-byte aligned (enables vector access).

@@ -748,7 +748,11 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   hipLaunchKernelGGL(k_reorder_offsets, grid, blk, 0, st, a, d_sm, hfirst, hcell);
   MONO_HIP(hipGetLastError());
   MONO_HIP(hipMemcpyAsync(h_sharded_slot_sizes, hist, (size_t)N * M * 4, hipMemcpyDeviceToHost, st));
+  uint32_t h_sort_err = 0;
+  if (uint32_t* w = sort_error_word())
+    MONO_HIP(hipMemcpyAsync(&h_sort_err, w, sizeof(h_sort_err), hipMemcpyDeviceToHost, st));
   MONO_HIP(hipStreamSynchronize(st));
+  MONO_TRY(sort_error_report(h_sort_err));  // the sizes come out of a sort: never hand out stale ones
   int64_t uniq = 0;
   for (int n = 0; n < N; ++n)
     for (int m = 0; m < M; ++m) {
@@ -850,8 +854,11 @@ int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* 
     hipLaunchKernelGGL(k_shard_offsets, grid, blk, 0, st, a, d_sm, hfirst, hcell, out_fid_offset);
   MONO_HIP(hipGetLastError());
   MONO_HIP(hipMemcpyAsync(h_out_counts, hist, (size_t)n_out * 4, hipMemcpyDeviceToHost, st));
+  uint32_t h_sort_err = 0;
+  if (uint32_t* w = sort_error_word())
+    MONO_HIP(hipMemcpyAsync(&h_sort_err, w, sizeof(h_sort_err), hipMemcpyDeviceToHost, st));
   MONO_HIP(hipStreamSynchronize(st));
-  return 0;
+  return sort_error_report(h_sort_err);
 }
 
 }  // extern "C"

@@ -382,8 +382,11 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
     }
     tpre[set][2 * l2] = sum0;
     tpre[set][2 * l2 + 1] = sum1;
+    if (timed_out) s_timed_out = 1;
     __syncthreads();
-    if (tile % kLbGroup == kLbGroup - 1)
+    // (a group total built from a wait that gave up is never published: the tiles behind it time
+    // out in turn and raise the error word themselves)
+    if (tile % kLbGroup == kLbGroup - 1 && !s_timed_out)
       for (int d = threadIdx.x; d < nd; d += kSortThreads)
         __hip_atomic_store(&grows[(size_t)g * kSortMaxDigits + d],
                            (tpre[0][d] + tpre[1][d] + tpre[2][d] + tpre[3][d] + ltot[d]) | kRowReady,
@@ -438,7 +441,32 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_fused(
   }
 }
 
-static uint32_t* g_sort_err = nullptr;  // sticky device word, allocated once per process
+// Sticky error word of the fused passes (1 = a look-back wait gave up, 2 = a ticket word was not
+// zero): a __device__ symbol, so no call ever allocates it; every GPU holds its own copy, the
+// pointer is resolved once per device. Consumers of a sort's output read it before they act on
+// that output (table.hip k_classify), and every host read-back of the product path reports it
+// (sort_error_check): a failed sort never turns into rows updated at the wrong slots.
+static __device__ uint32_t g_sort_err_word[64];
+constexpr int kMaxDevices = 64;
+static uint32_t* g_sort_err_ptr[kMaxDevices] = {};
+
+uint32_t* sort_error_word() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  if (!g_sort_err_ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_sort_err_word)) != hipSuccess) return nullptr;
+    g_sort_err_ptr[dev] = (uint32_t*)p;
+  }
+  return g_sort_err_ptr[dev];
+}
+
+// `h_word` holds the error word as copied to the host by the caller's own read-back.
+int sort_error_report(uint32_t h_word) {
+  if (h_word == 0) return 0;
+  return fail("radix sort failed on the device (code %u: %s); the batch it served was skipped",
+              h_word, h_word == 1 ? "a look-back wait timed out" : "a control word was not zero");
+}
 
 static bool fused_enabled() {
   static int on = -1;
@@ -482,10 +510,8 @@ int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uin
   uint32_t* tk = (uint32_t*)p;
   uint32_t* tv = tk + n_al;
   if (fused_enabled() && passes >= 2 && tiles <= kFusedMaxTiles && passes <= kFusedMaxPasses) {
-    if (!g_sort_err) {  // first fused sort of the process
-      MONO_HIP(hipMalloc((void**)&g_sort_err, 256));
-      MONO_HIP(hipMemsetAsync(g_sort_err, 0, 256, st));
-    }
+    uint32_t* const g_sort_err = sort_error_word();
+    MONO_REQUIRE(g_sort_err, "sort_pairs_u32: cannot resolve the error word of this device");
     char* q = (char*)(tv + n_al);
     q = (char*)(((uintptr_t)q + 255) & ~(uintptr_t)255);
     uint32_t* dhist = (uint32_t*)q;                                   // [passes][256]
@@ -565,10 +591,11 @@ int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uin
 }  // namespace mono
 
 extern "C" int mono_debug_sort_error(void) {
-  if (!mono::g_sort_err) return 0;
+  uint32_t* w = mono::sort_error_word();
+  if (!w) return -1;
   uint32_t v = 0;
   if (hipDeviceSynchronize() != hipSuccess ||
-      hipMemcpy(&v, mono::g_sort_err, 4, hipMemcpyDeviceToHost) != hipSuccess)
+      hipMemcpy(&v, w, 4, hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
   return (int)v;
 }

@@ -489,6 +489,8 @@ struct ApplyArgs {
   const uint4* heads;        // compacted (position, length, slot, first index) of the short
                              // segments, or nullptr
   const uint32_t* nheads;
+  const uint32_t* sort_err;  // sort.hip's sticky error word: non-zero = the sorted arrays are not
+                             // to be trusted, the batch is skipped (k_classify emits nothing)
 };
 
 // A key with many occurrences in one batch (a Zipf head): handed to a whole workgroup.
@@ -1019,6 +1021,9 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
   const uint32_t* __restrict__ sk = static_cast<const uint32_t*>(a.skeys);
   const int64_t n = a.n;
   const int tid = threadIdx.x, lane = tid & 63;
+  // a sort that failed (look-back time-out) leaves stale ping-pong data behind: emit no heads and
+  // no long segments, so that nothing is applied; the host reports the word at its next read-back
+  if (a.sort_err && *a.sort_err != 0u) return;
   if (tid == 0) s_cnt = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * (kClsThreads * kClsItems);
@@ -1438,7 +1443,16 @@ static uint64_t pow2_at_least(uint64_t x) {
   return p;
 }
 
+// Slots are 32-bit (kNoSlot = 0xFFFFFFFF, slots cap and cap + 1 hold the sentinel-valued keys) and
+// the write path sorts them on at most 32 bits: a table never grows past 2^31 slots per GPU
+// (1.29e9 rows at the 0.6 load bound); beyond that the call fails instead of truncating slots.
+constexpr uint64_t kMaxCap = 1ull << 31;
+
 static int alloc_arrays(TableDev* d, uint64_t cap) {
+  MONO_REQUIRE(cap <= kMaxCap,
+               "table of %llu slots exceeds the %llu-slot limit of 32-bit slot indices "
+               "(at most %.3g rows per GPU: shard the table over more GPUs)",
+               (unsigned long long)cap, (unsigned long long)kMaxCap, kMaxLoad * (double)kMaxCap);
   d->cap = cap;
   d->bucket_mask = cap / kBucket - 1;
   MONO_HIP(hipMalloc((void**)&d->keys, cap * sizeof(int64_t)));
@@ -1467,11 +1481,14 @@ static int reset_arrays(TableDev* d, hipStream_t st) {
 
 static int read_counters(Table* t, hipStream_t st, int64_t* live, int64_t* tombs) {
   unsigned long long h[2];
+  uint32_t h_err = 0;
   MONO_HIP(hipMemcpyAsync(h, t->d.counters, sizeof(h), hipMemcpyDeviceToHost, st));
+  if (uint32_t* w = sort_error_word())
+    MONO_HIP(hipMemcpyAsync(&h_err, w, sizeof(h_err), hipMemcpyDeviceToHost, st));
   MONO_HIP(hipStreamSynchronize(st));
   *live = (int64_t)h[0];
   *tombs = (int64_t)h[1];
-  return 0;
+  return sort_error_report(h_err);  // every host read-back of the write path reports a failed sort
 }
 
 // Rehash into a table of `new_cap` slots (drops tombstones). Peak memory = old + new arrays.
@@ -1517,6 +1534,8 @@ static int ensure_room(Table* t, int64_t incoming, hipStream_t st) {
   MONO_TRY(read_counters(t, st, &live, &tombs));
   if (live + tombs + incoming > limit) {
     uint64_t want = pow2_at_least((uint64_t)((double)(live + incoming) / kGrowTarget) + 1);
+    // near the slot-index limit settle for any capacity that keeps the load bound
+    if (want > kMaxCap && (double)(live + incoming) <= kMaxLoad * (double)kMaxCap) want = kMaxCap;
     MONO_TRY(rehash(t, want, st));
     tombs = 0;
   }
@@ -1717,6 +1736,7 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   a.filt = fd;
   a.assign_add_semantics = assign_add_semantics;
   a.global_step = global_step;
+  a.sort_err = from_keys ? nullptr : sort_error_word();
   for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
 
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
@@ -1804,6 +1824,7 @@ int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, con
   a.n = n;
   a.src = src;
   a.mode = MODE_ASSIGN_ADD;
+  a.sort_err = sort_error_word();
   MONO_TRY(t->ws.ensure(queue_bytes(n, D)));
   uint4* heads = nullptr;
   MONO_TRY(queue_setup(&a, (char*)t->ws.ptr, n, D, &heads, st));

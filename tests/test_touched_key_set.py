@@ -54,6 +54,27 @@ def test_random_streams_match_oracle(capacity, vocab, batch):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(120)
+@pytest.mark.parametrize("capacity,batch", [(1000, 6000), (1000, 50000), (3, 5000)])
+def test_batches_far_beyond_the_set_size(capacity, batch):
+  """A batch with several times more DISTINCT ids than the set has cells (2048 cells at capacity
+  1000): one round used to insert all of them before the overflow position was known, filled the
+  table and spun for ever. Rounds are now bounded by the free cells; drop positions and counts stay
+  the reference's (hopscotch_hash_set.cc:104-166 replayed by the oracle)."""
+  import torch
+  from monolith_amd.touched_key_set_ops import TouchedKeySet
+  rng = np.random.Generator(np.random.PCG64(7 * capacity + batch))
+  o, h = cpu.OracleKeySet(capacity), TouchedKeySet(capacity)
+  for step in range(4):
+    ids = rng.permutation(batch * 4)[:batch].astype(np.int64) - batch  # all distinct
+    if step == 2:
+      ids[::3] = ids[0]  # duplicates in between
+    assert h.insert(torch.from_numpy(ids)) == o.insert(ids.tolist()), step
+    assert h.size() == len(o.keys)
+  assert sorted(h.steal().cpu().tolist()) == o.steal()
+
+
+@pytest.mark.gpu
 def test_table_records_applied_ids():
   """Ids that pass the occurrence filter and are optimized land in the set; filtered ids and
   ids touched only by assign / lookup do not."""
