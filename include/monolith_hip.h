@@ -270,6 +270,16 @@ int mono_reduce_sum(const int64_t* row_ids, const float* values, int64_t n, int6
                     int64_t batch, float* out, void* stream);
 int mono_reduce_mean(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
                      int64_t batch, float* out, void* stream);
+/* No counterpart in the reference: mono_reduce_sum for callers that cannot allocate device memory
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc). Same
+ * arguments, same result, same errors; its scratch (sortedness flag, (row, position) pairs, radix
+ * sort temporaries) is a fixed 16 MiB __device__ array of the library, one copy per GPU, so the
+ * call never calls hipMalloc / hipFree or any allocating routine. Limits: n <= 524288 row ids per
+ * call (larger calls fail with a message naming mono_reduce_sum). All calls on one GPU share that
+ * array: calls that overlap on one GPU (two streams, two host threads) race; issue them one after
+ * the other. Like mono_reduce_sum it reads one flag word back (synchronises the stream). */
+int mono_reduce_sum_noalloc(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
+                            int64_t batch, float* out, void* stream);
 /* ops/reduce_op.cc:124-148 / :150-180. */
 int mono_reduce_sum_gradient(const int64_t* row_ids, const float* grads, int64_t n, int64_t dim,
                              int64_t batch, float* out, void* stream);

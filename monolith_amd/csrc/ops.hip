@@ -512,6 +512,88 @@ int mono_reduce_sum(const int64_t* row_ids, const float* values, int64_t n, int6
                                     "mono_reduce_sum", (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------- mono_reduce_sum_noalloc
+// mono_reduce_sum for callers that cannot allocate (code under HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc): the same kernels, with the scratch the existing entry
+// point takes from a growable workspace (flag word, (row, position) pairs, radix-sort temporaries)
+// in a file-scope __device__ array instead. Every GPU the library runs on holds its own copy of
+// that array until the process ends; its address is resolved once per device.
+constexpr int64_t kNoAllocMaxRows = 1 << 19;        // row ids per call
+constexpr size_t kNoAllocScratchBytes = 16u << 20;  // 16 MiB per GPU
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+constexpr int kNoAllocMaxDevices = 64;
+static unsigned char* g_scratch_ptr[kNoAllocMaxDevices] = {};
+
+// The array's name is only a host-side handle: kernels, memsets and copies get the device address
+// this returns, never `scratch` itself.
+static int noalloc_scratch(unsigned char** out) {
+  int dev = -1;
+  MONO_HIP(hipGetDevice(&dev));
+  MONO_REQUIRE(dev >= 0 && dev < kNoAllocMaxDevices, "mono_reduce_sum_noalloc: device %d out of range", dev);
+  if (!g_scratch_ptr[dev]) {  // once per device, with that device current
+    void* p = nullptr;
+    MONO_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    MONO_REQUIRE(p, "mono_reduce_sum_noalloc: no address for the scratch array on device %d", dev);
+    g_scratch_ptr[dev] = (unsigned char*)p;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+
+int mono_reduce_sum_noalloc(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
+                            int64_t batch, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  MONO_REQUIRE(dim > 0 && batch >= 0 && n >= 0, "mono_reduce_sum_noalloc: bad shape");
+  MONO_REQUIRE(n <= kNoAllocMaxRows,
+               "mono_reduce_sum_noalloc: %lld row ids exceed the %lld this entry point's fixed "
+               "scratch serves; use mono_reduce_sum",
+               (long long)n, (long long)kNoAllocMaxRows);
+  MONO_REQUIRE(batch < (int64_t)0xFFFFFFF0ll, "mono_reduce_sum_noalloc: batch %lld too large",
+               (long long)batch);
+  if (batch == 0) return 0;
+  MONO_REQUIRE(out && (n == 0 || (row_ids && values)), "mono_reduce_sum_noalloc: null buffer");
+  unsigned char* base = nullptr;
+  MONO_TRY(noalloc_scratch(&base));
+  // layout: [0, 256) flag word | four uint32 arrays of n_al | sort temporaries
+  const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
+  const int end_bit = bits_for_u((uint64_t)batch);
+  const size_t tmp_bytes = sort_pairs_tmp_bytes((size_t)n, end_bit);
+  const size_t off_tmp = (256 + 4 * n_al * sizeof(uint32_t) + 255) & ~(size_t)255;
+  MONO_REQUIRE(off_tmp + tmp_bytes <= kNoAllocScratchBytes,
+               "mono_reduce_sum_noalloc: %zu bytes of scratch needed, %zu available",
+               off_tmp + tmp_bytes, kNoAllocScratchBytes);
+  int* flags = (int*)base;
+  uint32_t* kin = (uint32_t*)(base + 256);
+  uint32_t* iin = kin + n_al;
+  uint32_t* kout = iin + n_al;
+  uint32_t* iout = kout + n_al;
+  // The array keeps the previous call's contents. What must start at zero: the flag word (cleared
+  // here); the radix sort's control words are cleared by its own first kernel; everything else is
+  // written before it is read.
+  int h_flags = 0;
+  MONO_HIP(hipMemsetAsync(flags, 0, sizeof(int), st));
+  if (n > 0)
+    hipLaunchKernelGGL(k_check_sorted<int64_t>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st,
+                       row_ids, n, batch, flags);
+  MONO_HIP(hipMemcpyAsync(&h_flags, flags, sizeof(int), hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipStreamSynchronize(st));
+  MONO_REQUIRE(!(h_flags & 2), "mono_reduce_sum_noalloc: a row id is outside [0, %lld)", (long long)batch);
+  SortedRows<int64_t> sr;
+  if (!(h_flags & 1)) {
+    sr.rows = row_ids;
+  } else {
+    hipLaunchKernelGGL(k_keys_to_u32<int64_t>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, row_ids,
+                       n, kin, iin);
+    MONO_TRY(sort_pairs_u32(kin, kout, iin, iout, (size_t)n, end_bit, base + off_tmp, tmp_bytes, st));
+    sr.urows = kout;
+    sr.perm = iout;
+  }
+  hipLaunchKernelGGL((k_segment_reduce<int64_t, false>), dim3(grid_for(batch * dim, 256)), dim3(256),
+                     0, st, sr, values, n, dim, batch, single_split(out, dim));
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
 int mono_reduce_mean(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
                      int64_t batch, float* out, void* stream) {
   return run_reduce<int64_t, true>(row_ids, values, n, dim, batch, single_split(out, dim),

@@ -103,6 +103,31 @@ struct Table {
   int64_t* cache_ids = nullptr;
   uint32_t* cache_slots = nullptr;
   int64_t cache_n = 0, cache_cap = 0;
+  // Prepared update order ("lookup, then update the same ids": the training step). When the calls
+  // on this table follow that pattern, mono_table_lookup resolves the slots first (k_probe), and
+  // the grouping of the positions by slot that the update needs (radix sort + k_classify) runs
+  // on a stream of its own BESIDE the row gather of the same lookup: the sort is latency-bound and
+  // leaves HBM idle, the gather is the opposite. The write call then checks on the device that
+  // the ids are still the ones the lookup saw and that all of them were found (k_verify, one
+  // 8-byte read-back), and goes straight to the apply kernels; anything else takes the full path.
+  // Valid under the slot record's conditions (no rehash / evict / clear since the lookup).
+  struct Prep {
+    Workspace ws;                 // sorted slots | positions | sort scratch | queues + heads
+    int64_t n = 0;                // positions the prepared order covers; 0 = none
+    uint32_t* sslots = nullptr;
+    uint32_t* sidx = nullptr;
+    char* q_base = nullptr;
+    int mode_class = -1;          // what k_classify was run for (-1: not run)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_probe = nullptr, ev_ready = nullptr, ev_verify = nullptr;
+    uint32_t* d_flags = nullptr;  // [0] ids the lookup did not find  [1] positions k_verify found changed
+    uint32_t* h_flags = nullptr;  // pinned host copy
+    uint32_t seen_changed = 0;    // d_flags[1] as of the last read-back (it only grows)
+  } prep;
+  bool expect_update = false;     // the last update used the ids of the lookup before it
+  int lookups_since_update = 0;
+  int last_mode_class = 1;
+  const void* last_lookup_ids = nullptr;
   int64_t max_update_ts = 0;
   int32_t* slot_expire_dev = nullptr;
   Workspace ws;
@@ -328,6 +353,101 @@ __global__ void __launch_bounds__(256) k_lookup(TableDev t, const int64_t* __res
         if (i0 + q < n) vstore<V>(out + (i0 + q) * D + e, r[q]);
     }
   }
+}
+
+// mono_table_lookup in two kernels (prepared update order, see Table::Prep): k_probe resolves
+// and records the slot of every position, k_gather_rows copies the rows. Together they move what
+// k_lookup moves plus a re-read of the 4-byte slots.
+constexpr int kIlpP = 8;  // one id per lane of the sub-group
+__global__ void __launch_bounds__(256) k_probe(TableDev t, const int64_t* __restrict__ ids, int64_t n,
+                                               int64_t* __restrict__ cache_ids,
+                                               uint32_t* __restrict__ cache_slots,
+                                               uint32_t* __restrict__ flags,
+                                               uint32_t* __restrict__ zero8) {
+  if (blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;  // counters of the prepared queues
+  const int sub = lane_sub(), gshift = lane_gshift();
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
+  uint32_t missed = 0;
+  for (int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8) * kIlpP; i0 < n;
+       i0 += ngroups * kIlpP) {
+    // lane q of the sub-group loads id q (one coalesced 64-byte read) and hands it round
+    const int64_t mine = i0 + sub < n ? ids[i0 + sub] : kEmpty;
+    int64_t key[kIlpP], k0[kIlpP];
+    uint64_t b[kIlpP];
+#pragma unroll
+    for (int q = 0; q < kIlpP; ++q) key[q] = __shfl(mine, q, 8);
+#pragma unroll
+    for (int q = 0; q < kIlpP; ++q) {
+      b[q] = mix64((uint64_t)key[q]) & t.bucket_mask;
+      k0[q] = t.keys[b[q] * kBucket + sub];
+    }
+    uint32_t my_slot = kNoSlot;
+#pragma unroll
+    for (int q = 0; q < kIlpP; ++q) {
+      const uint32_t sl = group_find_pre(t, key[q], b[q], k0[q], sub, gshift);
+      if (sub == q) my_slot = sl;
+    }
+    if (i0 + sub < n) {
+      cache_ids[i0 + sub] = mine;
+      cache_slots[i0 + sub] = my_slot;
+      missed += my_slot == kNoSlot;
+    }
+  }
+  const unsigned long long any = __ballot(missed != 0);
+  if (any) {  // rare: one atomic per lane that saw a miss
+    if (missed) atomicAdd(&flags[0], missed);
+  }
+}
+
+// out[i, :] = row of slot[i] (zeros for kNoSlot). LPR lanes move one row, 16 bytes per lane and
+// step; kIlpG rows per lane group in flight.
+constexpr int kIlpG = 4;
+template <int LPR>
+__global__ void __launch_bounds__(256) k_gather_rows4(TableDev t, const uint32_t* __restrict__ slots,
+                                                      int64_t n, float* __restrict__ out) {
+  const int l = threadIdx.x % LPR;
+  const int64_t ngroups = (int64_t)gridDim.x * (256 / LPR);
+  const int D = t.dim, R = t.row_floats;
+  for (int64_t i0 = ((int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR) * kIlpG; i0 < n;
+       i0 += ngroups * kIlpG) {
+    uint32_t sl[kIlpG];
+#pragma unroll
+    for (int q = 0; q < kIlpG; ++q) sl[q] = i0 + q < n ? slots[i0 + q] : kNoSlot;
+    for (int e = l * 4; e < D; e += LPR * 4) {
+      float4 r[kIlpG];
+#pragma unroll
+      for (int q = 0; q < kIlpG; ++q)
+        r[q] = sl[q] != kNoSlot ? *reinterpret_cast<const float4*>(t.rows + (uint64_t)sl[q] * R + e)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int q = 0; q < kIlpG; ++q)
+        if (i0 + q < n) *reinterpret_cast<float4*>(out + (i0 + q) * D + e) = r[q];
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_gather_rows1(TableDev t, const uint32_t* __restrict__ slots,
+                                                      int64_t n, float* __restrict__ out) {
+  const int sub = lane_sub();
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
+  const int D = t.dim, R = t.row_floats;
+  for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8; i < n; i += ngroups) {
+    const uint32_t sl = slots[i];
+    for (int e = sub; e < D; e += 8) out[i * D + e] = sl != kNoSlot ? t.rows[(uint64_t)sl * R + e] : 0.f;
+  }
+}
+
+// flags[1] += 1 per wave that sees a position whose id is not the one the lookup recorded.
+__global__ void __launch_bounds__(256) k_verify(const int64_t* __restrict__ ids,
+                                                const int64_t* __restrict__ cache_ids, int64_t n,
+                                                uint32_t* __restrict__ flags,
+                                                uint32_t* __restrict__ handout) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *handout = 0;  // k_apply_long's queue cursor
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    bad = bad || ids[i] != cache_ids[i];
+  const unsigned long long m = __ballot(bad);
+  if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&flags[1], 1u);
 }
 
 __global__ void __launch_bounds__(256) k_contains(TableDev t, const int64_t* __restrict__ ids,

@@ -88,6 +88,10 @@ __global__ void __launch_bounds__(256) k_rmw(float4* __restrict__ tab, uint64_t 
       v[q].x += 1.f;
       tab[u[q] * L + l] = v[q];
       if (TSMODE == 1 && l == 0) ts[mix(u[q]) & ts_mask] = (uint32_t)i0;
+      // 3 / 4 / 5: a 16- / 32- / 64-byte stamp record at a random place of the stamp array
+      if (TSMODE == 3 && l == 0) reinterpret_cast<float4*>(ts)[mix(u[q]) & (ts_mask >> 2)] = v[q];
+      if (TSMODE == 4 && l < 2) reinterpret_cast<float4*>(ts)[((mix(u[q]) & (ts_mask >> 3)) << 1) + l] = v[q];
+      if (TSMODE == 5 && l < 4) reinterpret_cast<float4*>(ts)[((mix(u[q]) & (ts_mask >> 4)) << 2) + l] = v[q];
       if (TSMODE == 2 && l == 0) {
         uint64_t byte = (u[q] * W) & ~(uint64_t)1023;  // start of the row's 1-KiB block
         if (((u[q] * W) & 1023) == 0) byte += 512;      // not the row's own line
@@ -150,13 +154,14 @@ static void report(const char* name, int64_t n, double bytes_per, float ms) {
   fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool only_stamp = argc > 1 && argv[1][0] == 's';
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   size_t free_b, total_b;
   CK(hipMemGetInfo(&free_b, &total_b));
   printf("device memory: %.1f GiB free of %.1f GiB\n", free_b / 1073741824.0, total_b / 1073741824.0);
-  const uint64_t big = 1ull << 37;  // 128 GiB
+  const uint64_t big = only_stamp ? 1ull << 35 : 1ull << 37;  // 128 GiB (32 GiB for the stamp rows only)
   float4 *tab, *out;
   CK(hipMalloc(&tab, big));
   CK(hipMemset(tab, 0, big));
@@ -170,7 +175,7 @@ int main() {
   char nm[160];
 
   printf("\n[A] single random reads, 32 GiB footprint, by access width\n");
-  {
+  if (!only_stamp) {
     const uint64_t fp = 1ull << 35;
     report("read 64 B  (ILP 8)", n, 64, timed([&] { k_read<64, 8><<<grid, 256>>>(tab, fp / 64 - 1, n, out); }));
     report("read 64 B  (ILP 16)", n, 64, timed([&] { k_read<64, 16><<<grid, 256>>>(tab, fp / 64 - 1, n, out); }));
@@ -182,18 +187,20 @@ int main() {
   }
   printf("\n[D] random 64-B reads by footprint\n");
   for (int lg : {27, 28, 30, 32, 34, 35, 37}) {
+    if (only_stamp) break;
     const uint64_t fp = 1ull << lg;
     snprintf(nm, sizeof nm, "read 64 B over %6.2f GiB", fp / 1073741824.0);
     report(nm, n, 64, timed([&] { k_read<64, 8><<<grid, 256>>>(tab, fp / 64 - 1, n, out); }));
   }
   printf("\n[D2] random 128-B reads by footprint\n");
   for (int lg : {27, 30, 35, 37}) {
+    if (only_stamp) break;
     const uint64_t fp = 1ull << lg;
     snprintf(nm, sizeof nm, "read 128 B over %6.2f GiB", fp / 1073741824.0);
     report(nm, n, 128, timed([&] { k_read<128, 8><<<grid, 256>>>(tab, fp / 128 - 1, n, out); }));
   }
   printf("\n[B] pairs of 64-B reads (32 GiB): second line inside the same aligned block\n");
-  {
+  if (!only_stamp) {
     const uint64_t lm = (1ull << 35) / 64 - 1;
     struct { int blk, delta; } cs[] = {{2, 1}, {4, 1}, {4, 2}, {8, 4}, {16, 8}, {16, 1}, {32, 16}, {64, 32},
                                        {128, 64}, {1024, 512}, {0, 0}};
@@ -215,11 +222,15 @@ int main() {
     report("rmw 128 B", m, 256, timed([&] { k_rmw<128, 4, 0><<<grid, 256>>>(tab, fp / 128 - 1, m, ts, ts_n - 1); }));
     report("rmw 128 B + 4-B stamp, random place of a 1-GiB array", m, 260, timed([&] { k_rmw<128, 4, 1><<<grid, 256>>>(tab, fp / 128 - 1, m, ts, ts_n - 1); }));
     report("rmw 128 B + 4-B stamp in the row's 1-KiB block", m, 260, timed([&] { k_rmw<128, 4, 2><<<grid, 256>>>(tab, fp / 128 - 1, m, ts, ts_n - 1); }));
+    report("rmw 128 B + 16-B stamp record, random place of a 1-GiB array", m, 272, timed([&] { k_rmw<128, 4, 3><<<grid, 256>>>(tab, fp / 128 - 1, m, ts, ts_n - 1); }));
+    report("rmw 128 B + 32-B stamp record, random place of a 1-GiB array", m, 288, timed([&] { k_rmw<128, 4, 4><<<grid, 256>>>(tab, fp / 128 - 1, m, ts, ts_n - 1); }));
+    report("rmw 128 B + 64-B stamp record, random place of a 1-GiB array", m, 320, timed([&] { k_rmw<128, 4, 5><<<grid, 256>>>(tab, fp / 128 - 1, m, ts, ts_n - 1); }));
     report("rmw 256 B", m, 512, timed([&] { k_rmw<256, 4, 0><<<grid, 256>>>(tab, fp / 256 - 1, m, ts, ts_n - 1); }));
     report("rmw 512 B", m, 1024, timed([&] { k_rmw<512, 2, 0><<<grid, 256>>>(tab, fp / 512 - 1, m, ts, ts_n - 1); }));
   }
   printf("\n[F] ascending sparse sweep of 64-B lines (one line per `stride` lines), 32 GiB span at most\n");
   for (int stride : {2, 8, 20, 64, 256}) {
+    if (only_stamp) break;
     int64_t m = n;
     while ((uint64_t)m * stride * 64 > (1ull << 35)) m >>= 1;
     snprintf(nm, sizeof nm, "sweep: one 64-B line per %d lines", stride);
