@@ -343,17 +343,20 @@ def main():
   update_bytes = n * (8 + 4 * D) + uniq * n * (8 + 2 * (4 * D + 4 * D) + 4)
   # per kernel: resolve (k_claim_pending) = id + handed-over (id, slot) read, slot write; apply = grad rows +
   # row/state read+write + ts (the part of §8d's update figure this kernel moves)
+  # (mono_table_lookup = k_probe + k_gather_rows once the lookup -> update pattern is seen: the
+  # sort of the update order then runs beside the row gather, and the update's "resolve" is
+  # k_verify + an 8-byte read-back, its "sort" the residual wait for the prepared order)
   kern = {
       "k_lookup": (lk_ms, lookup_bytes),
-      "k_claim_pending": (find_ms, n * (8 + 8 + 4) + n * 4),
-      "radix_sort(slot,idx)": (sort_ms, 0),
+      "resolve (k_verify / k_claim_pending)": (find_ms, n * (8 + 8)),
+      "sort (residual wait when prepared)": (sort_ms, 0),
       "apply phase": (apply_ms, n * 4 * D + uniq * n * (2 * (4 * D + 4 * D) + 4)),
   }
   if kapply_ms == kapply_ms:  # the kernel alone: what rocprofv3 reports as mono::k_apply<2, 1, 3>
     kern["k_apply"] = (kapply_ms, (n - n_long) * 4 * D + (uniq * n - u_long) * (2 * (4 * D + 4 * D) + 4))
   else:
     kern["k_apply"] = kern["apply phase"]
-  dom = max(("k_lookup", "k_claim_pending", "k_apply"), key=lambda k: kern[k][0])
+  dom = max(("k_lookup", "k_apply"), key=lambda k: kern[k][0])
   achieved = kern[dom][1] / (kern[dom][0] * 1e-3) / 1e9
   step_gbs = (lookup_bytes + update_bytes) / (ms_per_step * 1e-3) / 1e9
   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE,
@@ -362,7 +365,7 @@ def main():
   try:
     with open(os.path.join(ROOT, "profiles", "r01_i_pmc_summary.json")) as f:
       pmc = json.load(f)["kernels"]
-    members = {"k_lookup": ["mono::k_lookup<4>"], "k_claim_pending": ["mono::k_claim_pending"],
+    members = {"k_lookup": ["mono::k_lookup<4>"],
                "k_apply": ["mono::k_apply<2, 1, 3>"] if kapply_ms == kapply_ms else
                           ["mono::k_classify", "mono::k_apply<2, 1, 3>", "mono::k_apply_long<1, 3>",
                            "mono::k_combine<1>"]}[dom]

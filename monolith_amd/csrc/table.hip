@@ -123,11 +123,14 @@ struct Table {
     uint32_t* d_flags = nullptr;  // [0] ids the lookup did not find  [1] positions k_verify found changed
     uint32_t* h_flags = nullptr;  // pinned host copy
     uint32_t seen_changed = 0;    // d_flags[1] as of the last read-back (it only grows)
+    bool chain_pending = false;   // a sort + classify chain was launched and the caller's stream
+                                  // has not waited for it since
   } prep;
-  bool expect_update = false;     // the last update used the ids of the lookup before it
+  bool expect_update = false;     // the last update came right after one lookup of as many ids
   int lookups_since_update = 0;
+  int prep_strikes = 0;           // prepared orders in a row that the update could not use
+  int updates_since_strike = 0;
   int last_mode_class = 1;
-  const void* last_lookup_ids = nullptr;
   int64_t max_update_ts = 0;
   int32_t* slot_expire_dev = nullptr;
   Workspace ws;
@@ -401,8 +404,7 @@ __global__ void __launch_bounds__(256) k_probe(TableDev t, const int64_t* __rest
 
 // out[i, :] = row of slot[i] (zeros for kNoSlot). LPR lanes move one row, 16 bytes per lane and
 // step; kIlpG rows per lane group in flight.
-constexpr int kIlpG = 4;
-template <int LPR>
+template <int LPR, int kIlpG>
 __global__ void __launch_bounds__(256) k_gather_rows4(TableDev t, const uint32_t* __restrict__ slots,
                                                       int64_t n, float* __restrict__ out) {
   const int l = threadIdx.x % LPR;
@@ -1614,6 +1616,7 @@ static int read_counters(Table* t, hipStream_t st, int64_t* live, int64_t* tombs
 // Rehash into a table of `new_cap` slots (drops tombstones). Peak memory = old + new arrays.
 static int rehash(Table* t, uint64_t new_cap, hipStream_t st) {
   t->cache_n = 0;  // every key moves
+  t->prep.n = 0;
   TableDev nw = t->d;
   nw.keys = nullptr; nw.ts = nullptr; nw.rows = nullptr; nw.special = nullptr; nw.counters = nullptr;
   MONO_TRY(alloc_arrays(&nw, new_cap));
@@ -1735,12 +1738,29 @@ static void launch_short(const Table* t, const ApplyArgs& a, hipStream_t st) {
   else launch_apply_v<4>(t, a, st);
 }
 
-static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, hipStream_t st) {
-  const bool walks =
-      a.mode == MODE_ASSIGN_ADD || a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP;
+// What k_classify's output depends on besides the sorted arrays: 0 = no long segments (assign,
+// import), 1 = long segments, split into chunks (assign_add, dedup), 2 = long segments, whole
+// (per-occurrence optimizer steps).
+static int mode_class(int mode) {
+  return mode == MODE_OPT_SEQ ? 2 : (mode == MODE_ASSIGN_ADD || mode == MODE_OPT_DEDUP) ? 1 : 0;
+}
+static bool long_allowed(const Table* t, int mode, int64_t n) {
   // (a serving entry re-encodes after every add: its segments are walked whole, never chunked)
-  const bool allow_long = walks && a.n > kLongSeg && t->d.dim <= kLongMaxDim && !t->d.serving &&
-                          !t->d.any_sr;
+  return mode_class(mode) != 0 && n > kLongSeg && t->d.dim <= kLongMaxDim && !t->d.serving &&
+         !t->d.any_sr;
+}
+static void launch_classify(const ApplyArgs& a, bool allow_long, uint4* heads, hipStream_t st) {
+  const int64_t per_block = (int64_t)kClsThreads * kClsItems;
+  hipLaunchKernelGGL(k_classify, dim3((unsigned)((a.n + per_block - 1) / per_block)),
+                     dim3(kClsThreads), 0, st, a, allow_long ? 1 : 0, heads);
+}
+
+// classified: k_classify has already run on these sorted arrays (for this mode's class)
+// `ready`: an event of another stream the (already classified) input still waits for; both apply
+// streams wait on it directly, so neither start pays a fork behind the other.
+static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, hipStream_t st,
+                        bool classified = false, hipEvent_t ready = nullptr) {
+  const bool allow_long = long_allowed(t, a.mode, a.n);
   const unsigned lgrid = (unsigned)std::min<int64_t>(a.n / kLongSeg + 1, 1024);
   if (a.from_keys) {
     // filter path: the sub-group kernel resolves / gates / claims and feeds the long queue
@@ -1748,12 +1768,11 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
     if (allow_long) launch_long_o(t, a, lgrid, st);
     return 0;
   }
-  const int64_t per_block = (int64_t)kClsThreads * kClsItems;
-  hipLaunchKernelGGL(k_classify, dim3((unsigned)((a.n + per_block - 1) / per_block)),
-                     dim3(kClsThreads), 0, st, a, allow_long ? 1 : 0, heads);
+  if (!classified) launch_classify(a, allow_long, heads, st);
   a.heads = heads;
   a.nheads = nheads;
   if (!allow_long) {
+    if (ready) MONO_HIP(hipStreamWaitEvent(st, ready, 0));
     launch_short(t, a, st);
     return 0;
   }
@@ -1765,6 +1784,7 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
   }
   static const bool serial = getenv("MONO_SERIAL_APPLY") != nullptr;  // profiling aid
   if (serial) {
+    if (ready) MONO_HIP(hipStreamWaitEvent(st, ready, 0));
     launch_long_o(t, a, lgrid, st);
     launch_short(t, a, st);
     return 0;
@@ -1774,8 +1794,10 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
   // dispatcher from the auxiliary stream; the other order leaves the long kernel to run
   // mostly after the short one has drained.
   MONO_HIP(hipEventRecord(t->ev_fork, st));
+  if (ready) MONO_HIP(hipStreamWaitEvent(st, ready, 0));
   launch_long_o(t, a, lgrid, st);
   MONO_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
+  if (ready) MONO_HIP(hipStreamWaitEvent(t->aux, ready, 0));
   if (t->profile) MONO_HIP(hipEventRecord(t->ev_k[0], t->aux));
   launch_short(t, a, t->aux);
   if (t->profile) {
@@ -1833,6 +1855,185 @@ static int bits_for(uint64_t max_value) {
   return b;
 }
 
+// ---- prepared update order (Table::Prep) ------------------------------------------------------
+static int prep_mode() {  // MONO_PREP: 0 = never, 1 = when the calls follow the pattern (default), 2 = always
+  static const int v = [] {
+    const char* e = getenv("MONO_PREP");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
+static int prep_setup(Table* t) {
+  Table::Prep& p = t->prep;
+  if (p.stream) return 0;
+  // (a high-priority stream changes nothing here: what delays the sort beside the gather is
+  // the depth of the memory queues, not the dispatch order — profiles/r02_b_step_timeline.txt)
+  MONO_HIP(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+  MONO_HIP(hipEventCreateWithFlags(&p.ev_probe, hipEventDisableTiming));
+  MONO_HIP(hipEventCreateWithFlags(&p.ev_ready, hipEventDisableTiming));
+  MONO_HIP(hipEventCreateWithFlags(&p.ev_verify, hipEventDisableTiming));
+  MONO_HIP(hipMalloc((void**)&p.d_flags, 256));
+  MONO_HIP(hipMemset(p.d_flags, 0, 256));
+  MONO_HIP(hipHostMalloc((void**)&p.h_flags, 64, hipHostMallocDefault));
+  p.h_flags[0] = p.h_flags[1] = 0;
+  return 0;
+}
+
+static void prep_destroy(Table* t) {
+  Table::Prep& p = t->prep;
+  if (p.stream) (void)hipStreamSynchronize(p.stream);
+  if (p.ev_probe) (void)hipEventDestroy(p.ev_probe);
+  if (p.ev_ready) (void)hipEventDestroy(p.ev_ready);
+  if (p.ev_verify) (void)hipEventDestroy(p.ev_verify);
+  if (p.stream) (void)hipStreamDestroy(p.stream);
+  if (p.d_flags) (void)hipFree(p.d_flags);
+  if (p.h_flags) (void)hipHostFree(p.h_flags);
+  p.ws.release();
+  p = Table::Prep{};
+}
+
+// mono_table_lookup, prepared form: k_probe on the caller's stream, then the row gather there
+// and the update order (sort by slot, k_classify) on the table's own stream beside it.
+static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, bool aligned,
+                           hipStream_t st) {
+  MONO_TRY(prep_setup(t));
+  Table::Prep& p = t->prep;
+  p.n = 0;
+  // (tried: the sort chain on the caller's stream and the gather beside it — the update's host
+  // read-back then sits behind the whole chain: 376 us per step against 357)
+  hipStream_t gs = st;        // row gather
+  hipStream_t ss = p.stream;  // sort + classify
+  // A lookup that follows another one with no update in between: the chain of the earlier
+  // lookup may still be running, and k_probe below resets the counters that chain's k_classify
+  // adds to (a stale increment would make the next k_apply read heads nobody wrote).
+  if (p.chain_pending) MONO_HIP(hipStreamWaitEvent(st, p.ev_ready, 0));
+  const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
+  const int end_bit = bits_for(t->d.cap + 1);
+  const size_t tmp_bytes = (sort_pairs_tmp_bytes((size_t)n, end_bit) + 255) & ~(size_t)255;
+  const size_t q_bytes = queue_bytes(n, t->d.dim);
+  MONO_TRY(p.ws.ensure(2 * n_al * sizeof(uint32_t) + tmp_bytes + q_bytes));
+  p.sslots = (uint32_t*)p.ws.ptr;
+  p.sidx = p.sslots + n_al;
+  void* tmp = p.sidx + n_al;
+  p.q_base = (char*)tmp + tmp_bytes;
+  hipLaunchKernelGGL(k_probe, dim3(grid_for(n, 32 * kIlpP)), dim3(256), 0, st, t->d, ids, n,
+                     t->cache_ids, t->cache_slots, p.d_flags, (uint32_t*)p.q_base);
+  MONO_HIP(hipGetLastError());
+  MONO_HIP(hipEventRecord(p.ev_probe, st));
+  // Row gather on the caller's stream, deliberately throttled: one workgroup per CU, two rows in
+  // flight per lane group. At full depth (4096 workgroups x 8 rows) the gather keeps hundreds of
+  // thousands of requests queued in the memory pipeline, every load of the latency-bound sort
+  // beside it waits behind them (its first kernel took 52 us instead of 7, stream priority or
+  // not: profiles/r02_a, r02_b), and nothing overlaps. Throttled, the gather takes ~2x longer but
+  // the sort runs inside it: 388 -> 365 us per step (profiles/r02_sweep_gather.txt).
+  const int D = t->d.dim;
+  static const int gather_blocks = [] {
+    const char* e = getenv("MONO_GATHER_BLOCKS");
+    return e ? atoi(e) : 256;
+  }();
+  static const int gather_ilp = [] {
+    const char* e = getenv("MONO_GATHER_ILP");
+    return e ? atoi(e) : 2;
+  }();
+#define MONO_GATHER(LPR, ILP)                                                                       \
+  hipLaunchKernelGGL((k_gather_rows4<LPR, ILP>), dim3(grid_for(n, (256 / LPR) * ILP, gather_blocks)), \
+                     dim3(256), 0, gs, t->d, t->cache_slots, n, out)
+#define MONO_GATHER_L(LPR)                                  \
+  do {                                                      \
+    if (gather_ilp <= 1) MONO_GATHER(LPR, 1);               \
+    else if (gather_ilp <= 2) MONO_GATHER(LPR, 2);          \
+    else if (gather_ilp <= 4) MONO_GATHER(LPR, 4);          \
+    else MONO_GATHER(LPR, 8);                               \
+  } while (0)
+  if (D % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) {
+    if (D <= 16) MONO_GATHER_L(4);
+    else if (D <= 32) MONO_GATHER_L(8);
+    else MONO_GATHER_L(16);
+  } else {
+    hipLaunchKernelGGL(k_gather_rows1, dim3(grid_for(n, 32, gather_blocks)), dim3(256), 0, gs, t->d,
+                       t->cache_slots, n, out);
+  }
+#undef MONO_GATHER_L
+#undef MONO_GATHER
+  MONO_HIP(hipGetLastError());
+  // update order beside it
+  MONO_HIP(hipStreamWaitEvent(ss, p.ev_probe, 0));
+  MONO_TRY(sort_pairs_u32(t->cache_slots, p.sslots, nullptr, p.sidx, (size_t)n, end_bit, tmp,
+                          tmp_bytes, ss));
+  ApplyArgs a{};
+  a.n = n;
+  a.skeys = p.sslots;
+  a.sidx = p.sidx;
+  a.mode = t->last_mode_class == 2 ? MODE_OPT_SEQ : t->last_mode_class == 1 ? MODE_OPT_DEDUP : MODE_ASSIGN;
+  a.sort_err = sort_error_word();
+  uint4* heads = nullptr;
+  MONO_TRY(queue_setup(&a, p.q_base, n, t->d.dim, &heads, ss, /*counters_cleared=*/true));
+  launch_classify(a, long_allowed(t, a.mode, n), heads, ss);
+  MONO_HIP(hipGetLastError());
+  p.mode_class = t->last_mode_class;
+  MONO_HIP(hipEventRecord(p.ev_ready, ss));
+  p.chain_pending = true;
+
+  p.n = n;
+  return 0;
+}
+
+// The write call's side: use the prepared order if it provably serves this call.
+static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t n, int mode,
+                        const float* lrs, int n_lrs, int64_t req_time, hipStream_t st,
+                        int64_t global_step, bool* tried, bool* used) {
+  *tried = *used = false;
+  Table::Prep& p = t->prep;
+  if (p.n == 0 || p.n != n || t->cache_n != n || mode == MODE_IMPORT) return 0;
+  *tried = true;
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev[0], st));
+  // device side: every id was found by the lookup, and the ids are still the same ones
+  hipLaunchKernelGGL(k_verify, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, st, ids, t->cache_ids, n,
+                     p.d_flags, (uint32_t*)p.q_base + 4);
+  MONO_HIP(hipGetLastError());
+  MONO_HIP(hipMemcpyAsync(p.h_flags, p.d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipEventRecord(p.ev_verify, st));
+  // the count of ids not found restarts here (k_probe only adds to it): behind the read-back, and
+  // ahead of the wait for the prepared order, where it costs nothing
+  MONO_HIP(hipMemsetAsync(p.d_flags, 0, sizeof(uint32_t), st));
+  MONO_HIP(hipEventSynchronize(p.ev_verify));
+  const bool changed = p.h_flags[1] != p.seen_changed;
+  p.seen_changed = p.h_flags[1];
+  if (p.h_flags[0] != 0 || changed) {  // unknown ids to insert, or other ids: full path
+    p.n = 0;  // (and never again from this order: the miss count has just been reset)
+    return 0;
+  }
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
+  const bool classified = p.mode_class == mode_class(mode);
+  // a prepared classification is consumed as it is: both apply streams wait for the prepared
+  // order themselves (launch_apply); otherwise this stream waits here and classifies again
+  if (!classified || t->profile) MONO_HIP(hipStreamWaitEvent(st, p.ev_ready, 0));
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev[2], st));
+
+  ApplyArgs a{};
+  a.n = n;
+  a.src = src;
+  a.mode = mode;
+  a.ts = (uint32_t)req_time;
+  a.global_step = global_step;
+  a.sort_err = sort_error_word();
+  for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
+  a.skeys = p.sslots;
+  a.sidx = p.sidx;
+  uint4* heads = nullptr;
+  // (prepared classification: its counters stand; k_verify has reset the hand-out cursor)
+  MONO_TRY(queue_setup(&a, p.q_base, n, t->d.dim, &heads, st, /*counters_cleared=*/classified));
+  MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st, classified,
+                        classified && !t->profile ? p.ev_ready : nullptr));
+  p.chain_pending = false;  // the caller's stream has waited for ev_ready on every path above
+  if (!classified) p.mode_class = mode_class(mode);  // the queues now hold this class
+  MONO_HIP(hipGetLastError());
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
+  *used = true;
+  return 0;
+}
+
 // The whole write path. `filter` gates inserts of unknown ids (nullptr / dummy = no gate).
 static int write_path(Table* t, void* filter, const int64_t* ids, const float* src,
                       const uint32_t* src_ts, int64_t n, int mode, const float* lrs, int n_lrs,
@@ -1841,10 +2042,26 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   if (n == 0) return 0;
   MONO_REQUIRE(n < (int64_t)0xFFFFFFF0ll, "batch of %lld ids exceeds the 32-bit index range",
                (long long)n);
-  MONO_TRY(ensure_room(t, n, st));
   FilterDev fd{};
   if (filter) MONO_TRY(filter_dev_view(filter, &fd, st));
   const bool from_keys = fd.kind != 0;
+  // "one lookup, then an update of as many ids" is what makes the next lookup prepare the update
+  // order; two prepared orders in a row that could not be used (other ids, ids to insert) switch
+  // it off again for a while
+  const bool pattern = !from_keys && mode != MODE_IMPORT && t->cache_n == n &&
+                       t->lookups_since_update == 1;
+  t->lookups_since_update = 0;
+  if (!from_keys && mode != MODE_IMPORT) t->last_mode_class = mode_class(mode);
+  bool tried = false, prepared = false;
+  if (!from_keys)
+    MONO_TRY(try_prepared(t, ids, src, n, mode, lrs, n_lrs, req_time, st, global_step, &tried,
+                          &prepared));
+  if (prepared) t->prep_strikes = 0;
+  else if (tried) ++t->prep_strikes;
+  if (++t->updates_since_strike >= 64) t->updates_since_strike = t->prep_strikes = 0;
+  t->expect_update = pattern && t->prep_strikes < 2;
+  if (prepared) return 0;
+  MONO_TRY(ensure_room(t, n, st));
 
   ApplyArgs a{};
   a.n = n;
@@ -2076,6 +2293,7 @@ int mono_table_destroy(void* table) {
   if (t->slot_expire_dev) (void)hipFree(t->slot_expire_dev);
   if (t->cache_ids) (void)hipFree(t->cache_ids);
   if (t->cache_slots) (void)hipFree(t->cache_slots);
+  prep_destroy(t);
   t->ws.release();
   for (int i = 0; i < 4; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
@@ -2144,6 +2362,11 @@ int mono_table_lookup(void* table, const int64_t* ids, int64_t n, float* out, vo
   } else {
     t->cache_n = 0;
   }
+  // a second lookup with no update in between: not the training pattern (any more)
+  if (++t->lookups_since_update > 1) t->expect_update = false;
+  t->prep.n = 0;  // the record it was built from is being overwritten
+  if (t->cache_n && prep_mode() != 0 && (t->expect_update || prep_mode() == 2))
+    return lookup_prepared(t, ids, n, out, aligned, st);
   int64_t* ci = t->cache_n ? t->cache_ids : nullptr;
   uint32_t* cs = t->cache_n ? t->cache_slots : nullptr;
   if (t->d.dim % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) launch_lookup<4>(t, ids, n, out, st, ci, cs);
@@ -2238,6 +2461,7 @@ int mono_table_clear(void* table, void* stream) {
   MONO_TRY(reset_arrays(&t->d, (hipStream_t)stream));
   t->used_upper = 0;
   t->cache_n = 0;
+  t->prep.n = 0;
   return 0;
 }
 
@@ -2245,6 +2469,7 @@ int mono_table_evict(void* table, int64_t max_update_time, void* stream) {
   MONO_REQUIRE(table, "mono_table_evict: null table");
   Table* t = (Table*)table;
   t->cache_n = 0;  // evicted slots may be claimed by other keys
+  t->prep.n = 0;
   hipLaunchKernelGGL(k_evict, dim3(grid_for((int64_t)t->d.cap + 2, 256)), dim3(256), 0,
                      (hipStream_t)stream, t->d, max_update_time);
   MONO_HIP(hipGetLastError());

@@ -272,6 +272,64 @@ def test_lookup_slot_cache_hazards():
   assert np.array_equal(orows.view(np.uint32), hrows.view(np.uint32))
 
 
+@pytest.mark.parametrize("name", ["adagrad16", "ftrl16", "adagrad64", "multi3", "sgd3"])
+def test_training_loop_prepared_update_order(name):
+  """lookup(ids) -> apply_gradients(ids) step after step: from the second step on the lookup
+  prepares the update order (table.hip Table::Prep: k_probe, sort + k_classify beside the row
+  gather) and the update only verifies it. Every step is the oracle's, bit for bit, across what
+  the prepared order has to survive: keys with thousands of occurrences (long segments, split
+  chunks), switches between dedup / per-occurrence / assign_add (the classification is redone),
+  steps that bring ids the table has never seen (the update falls back to the full path and
+  inserts them), a lookup that is not followed by its update, and a repeated update."""
+  cfg = CFGS[name]
+  o, h, _, _ = _pair(cfg)
+  D = sum(sg["dim"] for sg in cfg["segments"])
+  nlr = len(cfg["segments"])
+  rng = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode())))
+  n, vocab = 24000, 3000
+  lrs = [0.05, 0.02, 0.1][:nlr]
+  base = rng.integers(0, vocab, n).astype(np.int64)
+  o.assign_add(np.arange(vocab), np.zeros((vocab, D), np.float32), req_time=1)
+  h.assign_add(np.arange(vocab), np.zeros((vocab, D), np.float32), req_time=1)
+  probe = np.arange(-5, vocab + 4000, dtype=np.int64)
+  for step in range(12):
+    ids = base.copy()
+    ids[rng.integers(0, n, 6000)] = 7            # a hot key: ~6000 occurrences (> one chunk)
+    ids[rng.integers(0, n, 300)] = 11            # a long segment that is not split
+    if step in (5, 9):                           # ids nobody has seen: the full path inserts them
+      ids[rng.integers(0, n, 50)] = vocab + 100 * step + np.arange(50)
+    g = rng.normal(0, 0.1, (n, D)).astype(np.float32)
+    want, got = o.lookup(ids), h.lookup(ids)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), step
+    if step == 3:                                # a second lookup before the update
+      assert np.array_equal(o.lookup(probe).view(np.uint32), h.lookup(probe).view(np.uint32))
+      o.lookup(ids)
+      h.lookup(ids)
+    dedup = step % 3 != 1
+    if step == 7:
+      o.assign_add(ids, g, req_time=100 + step)
+      h.assign_add(ids, g, req_time=100 + step)
+    else:
+      o.apply_gradients(ids, g, lrs, req_time=100 + step, global_step=step, enable_dedup=dedup)
+      h.apply_gradients(ids, g, lrs, req_time=100 + step, global_step=step, enable_dedup=dedup)
+    if step == 10:                               # the same update once more, no lookup in between
+      o.apply_gradients(ids, g, lrs, req_time=200, global_step=step, enable_dedup=True)
+      h.apply_gradients(ids, g, lrs, req_time=200, global_step=step, enable_dedup=True)
+    # compared through the export (a lookup here would break the lookup -> update pattern that
+    # switches the prepared order on). The hot row went through the chunked sum whenever the mode
+    # sums (DESIGN deviation 1): that row within its bound, everything else exactly.
+    oi, orows, ots = o.export()
+    hi, hrows, hts = h.export()
+    assert np.array_equal(oi, hi) and np.array_equal(ots, hts), step
+    hot = (oi == 7) if (dedup or step in (7, 10)) else np.zeros(len(oi), bool)
+    assert np.array_equal(orows[~hot].view(np.uint32), hrows[~hot].view(np.uint32)), step
+    np.testing.assert_allclose(hrows[hot], orows[hot], rtol=1e-4, atol=1e-5)
+    if hot.any():                                # keep the two in step on the hot row
+      o.import_rows(oi[hot], hrows[hot], hts[hot])
+  _assert_same_state(o, h)
+  assert o.max_update_ts() == h.max_update_ts()
+
+
 def test_lookup_entry_and_extract_slot():
   """hash_table_ops_test.py:100-114 (entries of ids 0..2 parse, id 3 -> b""),
   embedding_hash_table_test.h:78-93 (the dump of an SGD dim-1 entry holding 1.0, byte for byte:
