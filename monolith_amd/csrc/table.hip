@@ -1192,41 +1192,35 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
                                       slotv[k], idxv[k]);
 }
 
-// Long segments: one 256-thread workgroup per key, split into roles. Waves 1-3 (192 loader
-// threads) gather occurrence rows two tiles ahead (register staging -> LDS; occurrence indices
-// are prefetched through an LDS ring so a row load never waits on an index load) and store
-// them COLUMN-major. Wave 0 only consumes: lane e reads column e four rows per ds_read_b128
-// and adds / steps in input order — bit-exact with the sequential reference. A lone wave
-// issues one VALU op per ~4 cycles, so the walk is kept at ~1.5 instructions per row; what is
-// left is the dependent floating-point chain itself.
+// Long segments: one 256-thread workgroup per key (or per chunk of a split key), split into
+// roles. Waves 1-3 (192 loader threads) gather the occurrence rows, 16 bytes per lane and load,
+// TWO tiles ahead of the consumer (two register stages, two LDS tiles; occurrence indices run
+// further ahead through an LDS ring, so a row load never waits on an index load): ~800 rows of
+// 64 bytes are in flight per workgroup, which is what hides an HBM round trip at the rate the
+// consumer walks. Wave 0 only consumes: lane e owns column e and adds / steps the rows of the
+// row-major LDS tile in input order, eight LDS reads in flight — bit-exact with the sequential
+// reference, one dependent floating-point add per row.
 constexpr int kLoaders = 192;
-constexpr int kLStage = 32;                 // floats staged per loader thread per tile
-constexpr int kLTile = kLoaders * kLStage;  // 6144 floats (24 KB) per tile
-constexpr int kLMaxRows = 2 * kLoaders;     // two prefetched indices per loader thread
-constexpr int kLPad = 4;                    // column stride = rows + 4 floats (16 B aligned)
-constexpr int kLBuf = kLTile + 64 * kLPad + 64;
+constexpr int kLTileFloats = 6144;             // 24 KB per LDS tile
+constexpr int kLStage4 = kLTileFloats / 4 / kLoaders;  // 8 float4 per loader thread per tile
+constexpr int kLMaxRows = 2 * kLoaders;        // rows per tile (two prefetched indices per thread)
+constexpr int kLIdxRing = 8;
 
 template <int OPTK, int MODE>
 __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
-  __shared__ __attribute__((aligned(16))) float tile[2][kLBuf];
-  __shared__ uint32_t idxs[4][kLMaxRows];
+  __shared__ __attribute__((aligned(16))) float tile[2][kLTileFloats];
+  __shared__ uint32_t idxs[kLIdxRing][kLMaxRows];
+  __shared__ uint32_t s_qi;
   const int D = t.dim, R = t.row_floats;
   const int tid = threadIdx.x;
   const bool loader = tid >= 64;
   const int lt = tid - 64;  // loader thread index
-  // rows per tile: a multiple of 4 (b128 reads), one index per loader thread
-  const int rpt = max(4, min(kLMaxRows, kLTile / D) & ~3);
-  const int cs = rpt + kLPad;  // column stride in floats
-  // loader element walk: f = k * kLoaders + lt -> (row, column) without per-element division
-  const int r0 = loader ? lt / D : 0, c0 = loader ? lt - r0 * D : 0;
-  const int dr = kLoaders / D, dc = kLoaders - dr * D;
+  const bool vec4 = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0;
   const uint32_t nq = *a.qcount;
   // The consumer wave is a lone dependent chain; when this kernel shares CUs with k_apply its
   // issue slots must not be arbitrated away, so it runs at raised wave priority.
   if (!loader) __builtin_amdgcn_s_setprio(3);
-  // Entries differ in length by 40x: they are handed out one at a time (a static stride left
-  // some workgroups with two 4096-row chunks while others idled).
-  __shared__ uint32_t s_qi;
+  // Entries differ in length by 40x: they are handed out one at a time.
   for (;;) {
     __syncthreads();
     if (tid == 0) s_qi = atomicAdd(&a.qcount[4], 1u);
@@ -1235,10 +1229,17 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
     if (qi >= nq) break;
     const LongSeg ls = a.queue[qi];
     float* row = t.rows + (uint64_t)ls.slot * R;
-    const int64_t ntiles = (ls.end - ls.first + rpt - 1) / rpt;
     for (int eb = 0; eb < D; eb += 64) {  // 64 columns per pass (one pass for dim <= 64)
+      const int Dw = min(64, D - eb);     // columns of this pass
+      // rows per tile; the per-thread walk over the tile's (row, column) cells, without a
+      // division per cell: cell k * kLoaders + lt, cells = float4 quads (vec4) or floats
+      const int rpt = max(1, min(kLMaxRows, kLTileFloats / Dw));
+      const int64_t ntiles = (ls.end - ls.first + rpt - 1) / rpt;
+      const int cpr = vec4 ? Dw / 4 : Dw;  // cells per row
+      const int r0 = loader ? lt / cpr : 0, c0 = loader ? lt - r0 * cpr : 0;
+      const int dr = kLoaders / cpr, dc = kLoaders - dr * cpr;
       const int e = eb + tid;
-      const bool owner = !loader && e < D;
+      const bool owner = !loader && tid < Dw;
       int kind = OPTK, segi = 0, st0 = D + e, st1 = 2 * D + e;
       if (OPTK == OPTK_MULTI && owner) {
         for (int z = 0; z < t.n_seg; ++z)
@@ -1275,127 +1276,115 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         const int64_t p = ls.first + tl * rpt + rr;
         return (loader && rr < rpt && p < ls.end) ? a.sidx[p] : 0u;
       };
-      auto issue = [&](float(&S)[kLStage], int64_t tl) {  // loaders: gather tile tl into registers
+      // loaders: gather tile tl into a register stage (16 bytes per cell in the vec4 form, else
+      // the same registers hold 4 x as many 4-byte cells)
+      auto issue = [&](float4(&S)[kLStage4], int64_t tl) {
         if (!loader || tl >= ntiles) return;
         const int rows = (int)min((int64_t)rpt, ls.end - (ls.first + tl * rpt));
-        const uint32_t* ix = idxs[tl & 3];
+        const uint32_t* ix = idxs[tl & (kLIdxRing - 1)];
         int r = r0, c = c0;
+        if (vec4) {
 #pragma unroll
-        for (int k = 0; k < kLStage; ++k) {
-          S[k] = (r < rows) ? a.src[(uint64_t)ix[r] * D + c] : 0.f;
-          r += dr;
-          c += dc;
-          if (c >= D) { c -= D; ++r; }
+          for (int k = 0; k < kLStage4; ++k) {
+            S[k] = (r < rows) ? *reinterpret_cast<const float4*>(a.src + (uint64_t)ix[r] * D + eb + 4 * c)
+                              : make_float4(0.f, 0.f, 0.f, 0.f);
+            r += dr;
+            c += dc;
+            if (c >= cpr) { c -= cpr; ++r; }
+          }
+        } else {
+          float* Sf = reinterpret_cast<float*>(&S[0]);
+#pragma unroll
+          for (int k = 0; k < 4 * kLStage4; ++k) {
+            Sf[k] = (r < rows) ? a.src[(uint64_t)ix[r] * D + eb + c] : 0.f;
+            r += dr;
+            c += dc;
+            if (c >= cpr) { c -= cpr; ++r; }
+          }
         }
       };
-      auto put = [&](const float(&S)[kLStage], int buf) {  // column-major store of columns [eb, eb+64)
+      auto put = [&](const float4(&S)[kLStage4], int buf) {  // row-major [row][Dw] store
         if (!loader) return;
         int r = r0, c = c0;
+        if (vec4) {
 #pragma unroll
-        for (int k = 0; k < kLStage; ++k) {
-          const int cc = c - eb;
-          if (r < rpt && cc >= 0 && cc < 64) tile[buf][cc * cs + r] = S[k];
-          r += dr;
-          c += dc;
-          if (c >= D) { c -= D; ++r; }
+          for (int k = 0; k < kLStage4; ++k) {
+            if (r < rpt) *reinterpret_cast<float4*>(&tile[buf][r * Dw + 4 * c]) = S[k];
+            r += dr;
+            c += dc;
+            if (c >= cpr) { c -= cpr; ++r; }
+          }
+        } else {
+          const float* Sf = reinterpret_cast<const float*>(&S[0]);
+#pragma unroll
+          for (int k = 0; k < 4 * kLStage4; ++k) {
+            if (r < rpt) tile[buf][r * Dw + c] = Sf[k];
+            r += dr;
+            c += dc;
+            if (c >= cpr) { c -= cpr; ++r; }
+          }
         }
+      };
+      auto step = [&](float v) {
+        if (MODE == MODE_ASSIGN_ADD) w += v;
+        else if (MODE == MODE_OPT_SEQ) opt_step(kind, sg, lr, v, w, s0, s1, ox);
+        else acc = acc + v;
       };
       auto compute = [&](int64_t tl, int buf) {  // wave 0: walk the tile in input order
         if (!owner) return;
         const int rows = (int)min((int64_t)rpt, ls.end - (ls.first + tl * rpt));
-        const float* tp = &tile[buf][tid * cs];
+        const float* tp = &tile[buf][tid];
         int r = 0;
         if (MODE == MODE_OPT_DEDUP && !have_acc) {  // first row seeds the sum
-          const float4 q = *reinterpret_cast<const float4*>(tp);
-          acc = q.x;
-          if (rows > 1) acc = acc + q.y;
-          if (rows > 2) acc = acc + q.z;
-          if (rows > 3) acc = acc + q.w;
+          acc = tp[0];
           have_acc = true;
-          r = 4;
+          r = 1;
         }
-        // 16 rows per step, software pipelined: the next step's four ds_read_b128 are in
-        // flight while the current 16 values are consumed.
-        auto consume = [&](const float4(&q)[4]) {
-          if (MODE == MODE_OPT_DEDUP) {
+        for (; r + 8 <= rows; r += 8) {  // eight LDS reads in flight, the adds stay in order
+          float v[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) acc = (((acc + q[k].x) + q[k].y) + q[k].z) + q[k].w;
-          } else if (MODE == MODE_ASSIGN_ADD) {
+          for (int k = 0; k < 8; ++k) v[k] = tp[(r + k) * Dw];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) w = (((w + q[k].x) + q[k].y) + q[k].z) + q[k].w;
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              opt_step(kind, sg, lr, q[k].x, w, s0, s1, ox);
-              opt_step(kind, sg, lr, q[k].y, w, s0, s1, ox);
-              opt_step(kind, sg, lr, q[k].z, w, s0, s1, ox);
-              opt_step(kind, sg, lr, q[k].w, w, s0, s1, ox);
-            }
-          }
-        };
-        if (r + 16 <= rows) {
-          float4 qa[4], qb[4];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) qa[k] = *reinterpret_cast<const float4*>(tp + r + 4 * k);
-          for (;;) {
-            const bool more_b = r + 32 <= rows;
-            if (more_b) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) qb[k] = *reinterpret_cast<const float4*>(tp + r + 16 + 4 * k);
-            }
-            consume(qa);
-            r += 16;
-            if (!more_b) break;
-            const bool more_a = r + 32 <= rows;
-            if (more_a) {
-#pragma unroll
-              for (int k = 0; k < 4; ++k) qa[k] = *reinterpret_cast<const float4*>(tp + r + 16 + 4 * k);
-            }
-            consume(qb);
-            r += 16;
-            if (!more_a) break;
-          }
+          for (int k = 0; k < 8; ++k) step(v[k]);
         }
-        for (; r < rows; ++r) {
-          const float v = tp[r];
-          if (MODE == MODE_ASSIGN_ADD) w += v;
-          else if (MODE == MODE_OPT_SEQ) opt_step(kind, sg, lr, v, w, s0, s1, ox);
-          else acc = acc + v;
-        }
+        for (; r < rows; ++r) step(tp[r * Dw]);
       };
-
-      __syncthreads();  // LDS of the previous segment / element block is free
-      if (loader) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          idxs[0][lt + h * kLoaders] = load_idx(0, h);
-          idxs[1][lt + h * kLoaders] = load_idx(1, h);
-          idxs[2][lt + h * kLoaders] = load_idx(2, h);
-        }
-      }
-      __syncthreads();
-      // One register stage: a round first parks the tile fetched during the previous round
-      // (its loads had a whole consumer round to land), then issues the next gather. Index
-      // prefetch runs one round further ahead (loaded in round t, parked in round t + 1).
-      float S[kLStage];
-      uint32_t nx0 = load_idx(3, 0), nx1 = load_idx(3, 1);
-      issue(S, 0);
-      put(S, 0);
-      issue(S, 1);
-      __syncthreads();
-      for (int64_t tl = 0; tl < ntiles; ++tl) {
-        // tile tl sits in LDS[tl & 1]; S carries tile tl + 1
+      // one round: tile tl sits in LDS[tl & 1]; stage S carries tile tl + 1, the other stage
+      // tile tl + 2. Park tl + 1, refill S with tl + 3, advance the index ring, consume tl.
+      uint32_t nx0 = 0, nx1 = 0;
+      auto round = [&](int64_t tl, float4(&S)[kLStage4]) {
         const int cur = (int)(tl & 1);
         if (tl + 1 < ntiles) put(S, cur ^ 1);
         if (loader) {
-          idxs[(tl + 3) & 3][lt] = nx0;
-          idxs[(tl + 3) & 3][lt + kLoaders] = nx1;
+          idxs[(tl + 4) & (kLIdxRing - 1)][lt] = nx0;
+          idxs[(tl + 4) & (kLIdxRing - 1)][lt + kLoaders] = nx1;
         }
-        nx0 = load_idx(tl + 4, 0);
-        nx1 = load_idx(tl + 4, 1);
-        issue(S, tl + 2);
+        nx0 = load_idx(tl + 5, 0);
+        nx1 = load_idx(tl + 5, 1);
+        issue(S, tl + 3);
         compute(tl, cur);
         __syncthreads();
+      };
+
+      __syncthreads();  // LDS of the previous segment / column pass is free
+      if (loader) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int z = 0; z < 4; ++z) idxs[z][lt + h * kLoaders] = load_idx(z, h);
+      }
+      __syncthreads();
+      float4 Sa[kLStage4], Sb[kLStage4];
+      nx0 = load_idx(4, 0);
+      nx1 = load_idx(4, 1);
+      issue(Sa, 0);
+      put(Sa, 0);
+      issue(Sb, 1);  // tile 1 -> parked by round 0
+      issue(Sa, 2);  // tile 2 -> parked by round 1
+      __syncthreads();
+      for (int64_t tl = 0; tl < ntiles; tl += 2) {
+        round(tl, Sb);
+        if (tl + 1 < ntiles) round(tl + 1, Sa);
       }
       if (owner && part) {
         a.partials[(uint64_t)ls.part * D + e] = MODE == MODE_ASSIGN_ADD ? w : acc;
