@@ -345,6 +345,21 @@ int mono_embedding_to_layout(const mono_layout_slice* h_slices, int n_slices,
                              const uint32_t* h_nfl_offset, int n_nfl, int32_t batch,
                              float* const* h_outs, const int64_t* h_out_floats, int n_outs,
                              void* stream);
+/* The fused form of "look up, then pool": PartitionedHashTable.lookup (distributed_ps.py:889-964)
+ * calls table.lookup per (table, ps) FID list (ops/hash_table_lookup_op.cc:36-73) and hands the
+ * [n_unique, dim] results to MonolithEmbeddingToLayout (ops/fused_embedding_to_layout.cc:403-695,
+ * GatherEmb :624-676). Here buffer i of the fid_offset high word is named by the table and the
+ * FID list instead (h_tables[i], device list h_fid_lists[i] of h_fid_counts[i] ids: V2 order, one
+ * list per (table, ps, feature)); rows are gathered from the table and pooled in one pass, an id
+ * the table does not hold contributes a row of zeros (lookup semantics), nothing of size
+ * [n_unique, dim] is written. Same outputs, bit for bit, as mono_table_lookup per list followed by
+ * mono_embedding_to_layout. */
+int mono_lookup_to_layout(const mono_layout_slice* h_slices, int n_slices, void* const* h_tables,
+                          const int64_t* const* h_fid_lists, const int64_t* h_fid_counts, int n_bufs,
+                          const uint64_t* fid_offset, int64_t n_fids, const int32_t* feature_offset,
+                          int64_t n_features, const uint32_t* h_nfl_offset, int n_nfl, int32_t batch,
+                          float* const* h_outs, const int64_t* h_out_floats, int n_outs,
+                          void* stream);
 /* ops/fused_embedding_to_layout.cc:703-976 (MonolithEmbeddingToLayoutGrad / V2). h_emb_grads[i]
  * (shaped like embedding buffer i) are zero-filled, then every (unique fid, slice) receives the
  * layout gradients of all its uses, summed in the reference's order (layout, slice, sample, fid).

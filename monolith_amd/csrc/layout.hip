@@ -38,7 +38,13 @@ struct BufDev {
   int dim;
   long long floats;
   long long gbase;  // offset of the buffer in the virtual concatenation of all buffers
+  // fused lookup + pool (mono_lookup_to_layout): the "buffer" is a table. Row i of the buffer is
+  // the table row of slot slots[i] (kNoSlotL = the id is not in the table: a row of zeros, as
+  // mono_table_lookup would have written), rows `stride` floats apart. nullptr: a dense buffer.
+  const uint32_t* slots;
+  int stride;
 };
+constexpr uint32_t kNoSlotL = 0xFFFFFFFFu;
 
 struct LayoutArgs {
   const SliceDev* slices;
@@ -68,26 +74,90 @@ __device__ __forceinline__ const float* slice_src(const LayoutArgs& a, uint64_t 
   const BufDev b = a.bufs[i1];
   const long long off = (long long)i2 * b.dim + start;
   if (off + dim > b.floats) return nullptr;
+  if (b.slots) {
+    const uint32_t slot = b.slots[i2];
+    return slot == kNoSlotL ? nullptr : b.ptr + (unsigned long long)slot * b.stride + start;
+  }
   return b.ptr + off;
 }
 
-// pooled value of column `col` of slice `sc` for feature run f (SUM / MEAN, "copy first")
-__device__ __forceinline__ float pooled(const LayoutArgs& a, const SliceDev& sc, int f, int col,
-                                        int* fnum_out) {
+// V floats of one row, moved as one access (V = 4: 16 bytes; the host checks alignment)
+template <int V>
+struct Val {
+  float x[V];
+};
+template <int V>
+__device__ __forceinline__ Val<V> val_load(const float* p) {
+  Val<V> r;
+  if (p == nullptr) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.x[i] = 0.f;
+  } else if (V == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    r.x[0] = q.x; r.x[1] = q.y; r.x[2 % V] = q.z; r.x[3 % V] = q.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) r.x[i] = p[i];
+  }
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void val_store(float* p, const Val<V>& r) {
+  if (V == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r.x[0], r.x[1 % V], r.x[2 % V], r.x[3 % V]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < V; ++i) p[i] = r.x[i];
+  }
+}
+// r = v + r, component-wise (the reference's "row + accumulator" order)
+template <int V>
+__device__ __forceinline__ void val_add_into(Val<V>& r, const Val<V>& v) {
+#pragma unroll
+  for (int i = 0; i < V; ++i) r.x[i] = v.x[i] + r.x[i];
+}
+
+// pooled value of columns [col, col + V) of slice `sc` for feature run f (SUM / MEAN, "copy
+// first"). Four descriptors, then four rows, are in flight at a time; the adds stay in FID order.
+template <int V>
+__device__ __forceinline__ Val<V> pooled(const LayoutArgs& a, const SliceDev& sc, int f, int col,
+                                         int* fnum_out) {
   const int fnum = fid_count_dev(a, f);
   *fnum_out = fnum;
-  if (fnum == 0) return 0.f;
+  Val<V> acc = val_load<V>(nullptr);
+  if (fnum == 0) return acc;
   const int p0 = a.feature_offset[f];
-  float acc = 0.f;
-  for (int q = 0; q < fnum; ++q) {
-    const float* src = slice_src(a, a.fid_offset[p0 + q], sc.start, sc.dim);
-    const float v = src ? src[col] : 0.f;
-    acc = q == 0 ? v : v + acc;
+  int q = 0;
+  for (; q + 4 <= fnum; q += 4) {
+    uint64_t fo[4];
+    const float* src[4];
+    Val<V> v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fo[u] = a.fid_offset[p0 + q + u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) src[u] = slice_src(a, fo[u], sc.start, sc.dim);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = val_load<V>(src[u] ? src[u] + col : nullptr);
+    if (q == 0) acc = v[0]; else val_add_into<V>(acc, v[0]);
+    val_add_into<V>(acc, v[1]);
+    val_add_into<V>(acc, v[2]);
+    val_add_into<V>(acc, v[3]);
   }
-  if (sc.pooling == MONO_POOL_MEAN) acc = acc / fnum;
+  for (; q < fnum; ++q) {
+    const float* src = slice_src(a, a.fid_offset[p0 + q], sc.start, sc.dim);
+    const Val<V> v = val_load<V>(src ? src + col : nullptr);
+    if (q == 0) acc = v; else val_add_into<V>(acc, v);
+  }
+  if (sc.pooling == MONO_POOL_MEAN) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc.x[i] = acc.x[i] / fnum;
+  }
   return acc;
 }
 
+// One thread per V consecutive output columns of one (group, sample). total_work and the
+// groups' work_base / width are in units of V floats.
+template <int V>
 __global__ void __launch_bounds__(256) k_layout_forward(LayoutArgs a) {
   for (long long wi = (long long)blockIdx.x * blockDim.x + threadIdx.x; wi < a.total_work;
        wi += (long long)gridDim.x * blockDim.x) {
@@ -98,7 +168,8 @@ __global__ void __launch_bounds__(256) k_layout_forward(LayoutArgs a) {
     }
     const GroupDev g = a.groups[lo];
     const long long local = wi - g.work_base;
-    const int b = (int)(local / g.width), k = (int)(local - (long long)b * g.width);
+    const int b = (int)(local / g.width);
+    const int k = (int)(local - (long long)b * g.width) * V;  // first column of this thread
     const SliceDev s0 = a.slices[g.s0];
     float* out = a.outs[s0.out_index] + (long long)b * s0.out_stride + s0.out_offset;
     if (s0.pooling == MONO_POOL_FIRSTN) {  // :657-662: out[seq * dim + col], zero padded
@@ -106,18 +177,18 @@ __global__ void __launch_bounds__(256) k_layout_forward(LayoutArgs a) {
       const int f = s0.shared ? s0.f0 : s0.f0 + b;
       if (seq < fid_count_dev(a, f)) {
         const float* src = slice_src(a, a.fid_offset[a.feature_offset[f] + seq], s0.start, s0.dim);
-        if (src) out[k] = src[col];
+        if (src) val_store<V>(out + k, val_load<V>(src + col));
       }
       continue;
     }
     if (!s0.addn) {
       int fnum;
-      const float v = pooled(a, s0, s0.shared ? s0.f0 : s0.f0 + b, k, &fnum);
-      if (fnum) out[k] = v;
+      const Val<V> v = pooled<V>(a, s0, s0.shared ? s0.f0 : s0.f0 + b, k, &fnum);
+      if (fnum) val_store<V>(out + k, v);
       continue;
     }
     // ADDN (:553-598): the layout's slices accumulate into the zero-filled output in order
-    float cur = 0.f;
+    Val<V> cur = val_load<V>(nullptr);
     for (int si = g.s0; si < g.s1; ++si) {
       const SliceDev sc = a.slices[si];
       if (!sc.feature_num) continue;
@@ -128,18 +199,18 @@ __global__ void __launch_bounds__(256) k_layout_forward(LayoutArgs a) {
         // pooled value of the nearest earlier non-empty sample. Reproduced.
         while (f > sc.f0 && fid_count_dev(a, f) == 0) --f;
         int fnum;
-        const float t = pooled(a, sc, f, k, &fnum);
-        cur = sc.first ? t : t + cur;
+        const Val<V> t = pooled<V>(a, sc, f, k, &fnum);
+        if (sc.first) cur = t; else val_add_into<V>(cur, t);
       } else {  // SUM: every fid is added straight into the output
         const int fnum = fid_count_dev(a, f);
         const int p0 = a.feature_offset[f];
         for (int q = 0; q < fnum; ++q) {
           const float* src = slice_src(a, a.fid_offset[p0 + q], sc.start, sc.dim);
-          cur = (src ? src[k] : 0.f) + cur;
+          val_add_into<V>(cur, val_load<V>(src ? src + k : nullptr));
         }
       }
     }
-    out[k] = cur;
+    val_store<V>(out + k, cur);
   }
 }
 
@@ -243,7 +314,8 @@ struct HostPlan {
   std::vector<SliceDev> slices;
   std::vector<GroupDev> groups;
   std::vector<BufDev> bufs;
-  long long total_work = 0;
+  long long total_work = 0;  // forward work items, in units of `vec` floats
+  int vec = 1;               // floats per forward thread (4 when every access is 16-byte aligned)
 };
 
 static int build_plan(const mono_layout_slice* h_slices, int n_slices, float* const* emb_ptrs,
@@ -287,9 +359,27 @@ static int build_plan(const mono_layout_slice* h_slices, int n_slices, float* co
   long long gb = 0;
   hp->bufs.resize(n_bufs);
   for (int i = 0; i < n_bufs; ++i) {
-    hp->bufs[i] = BufDev{emb_ptrs[i], h_emb_dims[i], (long long)h_emb_floats[i], gb};
+    hp->bufs[i] = BufDev{emb_ptrs[i], h_emb_dims[i], (long long)h_emb_floats[i], gb, nullptr,
+                         h_emb_dims[i]};
     gb += h_emb_floats[i];
   }
+  return 0;
+}
+
+// Groups of forward work (after hp->bufs is final: their alignment decides the vector width).
+static int finish_plan(HostPlan* hp, int32_t batch, const char* who, float* const* h_outs = nullptr) {
+  const int n_slices = (int)hp->slices.size();
+  // 16-byte accesses need every column range, output offset and row start to be a multiple of 4
+  // floats and every base pointer 16-byte aligned
+  int vec = h_outs ? 4 : 1;
+  for (const SliceDev& sl : hp->slices) {
+    if ((sl.start | sl.dim | sl.out_offset | sl.out_stride) & 3) vec = 1;
+    if (h_outs && (reinterpret_cast<uintptr_t>(h_outs[sl.out_index]) & 15)) vec = 1;
+  }
+  for (const BufDev& bd : hp->bufs)
+    if ((bd.dim & 3) || (bd.stride & 3) || (reinterpret_cast<uintptr_t>(bd.ptr) & 15)) vec = 1;
+  hp->vec = vec;
+  hp->groups.clear();
   // groups: an ADDN layout is one group, every other slice its own
   long long work = 0;
   for (int i = 0; i < n_slices;) {
@@ -308,7 +398,7 @@ static int build_plan(const mono_layout_slice* h_slices, int n_slices, float* co
     if (live) {
       GroupDev g;
       g.s0 = i; g.s1 = j;
-      g.width = s.pooling == MONO_POOL_FIRSTN ? s.max_seq * s.dim : s.dim;
+      g.width = (s.pooling == MONO_POOL_FIRSTN ? s.max_seq * s.dim : s.dim) / vec;
       g.work_base = work;
       work += (long long)batch * g.width;
       if (g.width > 0) hp->groups.push_back(g);
@@ -359,6 +449,31 @@ static int upload_plan(const HostPlan& hp, const void* const* h_outs, int n_outs
   return 0;
 }
 
+// (shared by mono_embedding_to_layout and mono_lookup_to_layout)
+static int layout_forward(const HostPlan& hp, int n_slices, int n_bufs, const uint64_t* fid_offset,
+                               int64_t n_fids, const int32_t* feature_offset, int64_t n_features,
+                               int32_t batch, float* const* h_outs, const int64_t* h_out_floats,
+                               int n_outs, hipStream_t st) {
+  for (int o = 0; o < n_outs; ++o)
+    if (h_out_floats[o] > 0)
+      MONO_HIP(hipMemsetAsync(h_outs[o], 0, (size_t)h_out_floats[o] * sizeof(float), st));
+  if (hp.total_work == 0) return 0;
+  DevPlan dp;
+  MONO_TRY(upload_plan(hp, (const void* const*)h_outs, n_outs, 0, &dp, st));
+  LayoutArgs a{};
+  a.slices = dp.slices; a.groups = dp.groups; a.bufs = dp.bufs; a.outs = dp.outs;
+  a.n_slices = n_slices; a.n_groups = (int)hp.groups.size(); a.n_bufs = n_bufs;
+  a.fid_offset = fid_offset; a.n_fids = n_fids;
+  a.feature_offset = feature_offset; a.n_features = n_features;
+  a.batch = batch; a.total_work = hp.total_work;
+  if (hp.vec == 4)
+    hipLaunchKernelGGL(k_layout_forward<4>, dim3(grid_for(hp.total_work, 256)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_layout_forward<1>, dim3(grid_for(hp.total_work, 256)), dim3(256), 0, st, a);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace mono
 
 using namespace mono;
@@ -379,21 +494,64 @@ int mono_embedding_to_layout(const mono_layout_slice* h_slices, int n_slices,
   MONO_TRY(build_plan(h_slices, n_slices, const_cast<float* const*>(h_emb_ptrs), h_emb_dims,
                       h_emb_floats, n_bufs, h_nfl_offset, n_nfl, n_features, batch, n_outs,
                       h_out_floats, &hp, "mono_embedding_to_layout"));
-  for (int o = 0; o < n_outs; ++o)
-    if (h_out_floats[o] > 0)
-      MONO_HIP(hipMemsetAsync(h_outs[o], 0, (size_t)h_out_floats[o] * sizeof(float), st));
-  if (hp.total_work == 0) return 0;
-  DevPlan dp;
-  MONO_TRY(upload_plan(hp, (const void* const*)h_outs, n_outs, 0, &dp, st));
-  LayoutArgs a{};
-  a.slices = dp.slices; a.groups = dp.groups; a.bufs = dp.bufs; a.outs = dp.outs;
-  a.n_slices = n_slices; a.n_groups = (int)hp.groups.size(); a.n_bufs = n_bufs;
-  a.fid_offset = fid_offset; a.n_fids = n_fids;
-  a.feature_offset = feature_offset; a.n_features = n_features;
-  a.batch = batch; a.total_work = hp.total_work;
-  hipLaunchKernelGGL(k_layout_forward, dim3(grid_for(hp.total_work, 256)), dim3(256), 0, st, a);
-  MONO_HIP(hipGetLastError());
-  return 0;
+  MONO_TRY(finish_plan(&hp, batch, "mono_embedding_to_layout", h_outs));
+  return layout_forward(hp, n_slices, n_bufs, fid_offset, n_fids, feature_offset, n_features, batch,
+                        h_outs, h_out_floats, n_outs, st);
+}
+
+// Fused lookup + pool: the embedding "buffers" are tables and the FID lists that would have been
+// looked up into them. Every list is resolved to slots once (4 bytes per unique FID instead of a
+// row of the [n_unique, dim] lookup result), and the pooling kernel gathers the table rows
+// themselves: hash_table_lookup_op.cc:36-73 composed with fused_embedding_to_layout.cc:624-676.
+int mono_lookup_to_layout(const mono_layout_slice* h_slices, int n_slices, void* const* h_tables,
+                          const int64_t* const* h_fid_lists, const int64_t* h_fid_counts, int n_bufs,
+                          const uint64_t* fid_offset, int64_t n_fids, const int32_t* feature_offset,
+                          int64_t n_features, const uint32_t* h_nfl_offset, int n_nfl, int32_t batch,
+                          float* const* h_outs, const int64_t* h_out_floats, int n_outs,
+                          void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  MONO_REQUIRE(n_fids < (int64_t)0x7FFFFFF0ll && n_features < (int64_t)0x7FFFFFF0ll,
+               "mono_lookup_to_layout: more than 2^31 fids / features");
+  MONO_REQUIRE(n_bufs >= 0 && (n_bufs == 0 || (h_tables && h_fid_lists && h_fid_counts)),
+               "mono_lookup_to_layout: null argument");
+  // slots of every list, back to back
+  static Workspace slot_ws;
+  int64_t total = 0;
+  for (int i = 0; i < n_bufs; ++i) {
+    MONO_REQUIRE(h_tables[i] && h_fid_counts[i] >= 0 && (h_fid_counts[i] == 0 || h_fid_lists[i]),
+                 "mono_lookup_to_layout: bad buffer %d", i);
+    total += (h_fid_counts[i] + 63) & ~(int64_t)63;
+  }
+  MONO_TRY(slot_ws.ensure((size_t)total * sizeof(uint32_t) + 256));
+  std::vector<float*> ptrs(n_bufs);
+  std::vector<int32_t> dims(n_bufs), strides(n_bufs);
+  std::vector<int64_t> floats(n_bufs);
+  std::vector<const uint32_t*> slots(n_bufs);
+  int64_t off = 0;
+  for (int i = 0; i < n_bufs; ++i) {
+    uint32_t* sl = (uint32_t*)slot_ws.ptr + off;
+    MONO_TRY(table_resolve_slots(h_tables[i], h_fid_lists[i], h_fid_counts[i], sl, st));
+    const float* rows = nullptr;
+    int dim = 0, stride = 0;
+    MONO_TRY(table_row_view(h_tables[i], &rows, &dim, &stride));
+    ptrs[i] = const_cast<float*>(rows);
+    dims[i] = dim;
+    strides[i] = stride;
+    floats[i] = h_fid_counts[i] * (int64_t)dim;
+    slots[i] = sl;
+    off += (h_fid_counts[i] + 63) & ~(int64_t)63;
+  }
+  HostPlan hp;
+  MONO_TRY(build_plan(h_slices, n_slices, ptrs.data(), dims.data(), floats.data(), n_bufs,
+                      h_nfl_offset, n_nfl, n_features, batch, n_outs, h_out_floats, &hp,
+                      "mono_lookup_to_layout"));
+  for (int i = 0; i < n_bufs; ++i) {
+    hp.bufs[i].slots = slots[i];
+    hp.bufs[i].stride = strides[i];
+  }
+  MONO_TRY(finish_plan(&hp, batch, "mono_lookup_to_layout", h_outs));
+  return layout_forward(hp, n_slices, n_bufs, fid_offset, n_fids, feature_offset, n_features, batch,
+                        h_outs, h_out_floats, n_outs, st);
 }
 
 int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slices,
@@ -413,6 +571,7 @@ int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slice
   MONO_TRY(build_plan(h_slices, n_slices, h_emb_grads, h_emb_dims, h_emb_floats, n_bufs,
                       h_nfl_offset, n_nfl, n_features, batch, n_outs, h_out_floats, &hp,
                       "mono_embedding_to_layout_grad"));
+  MONO_TRY(finish_plan(&hp, batch, "mono_embedding_to_layout_grad"));
   long long total_floats = 0;
   for (int i = 0; i < n_bufs; ++i) {
     if (h_emb_floats[i] > 0)

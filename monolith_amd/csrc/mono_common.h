@@ -94,6 +94,12 @@ int sort_error_report(uint32_t h_word);
 int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, const float* src,
                      int D, bool aligned4, float* out, hipStream_t st);
 
+// table.hip, for the fused lookup + pool of layout.hip: the slot of every id (0xFFFFFFFF = not in
+// the table), and where the rows of a table live (weights first: columns [0, dim) of a row of
+// row_floats floats). The view is valid until the next call that can grow the table.
+int table_resolve_slots(void* table, const int64_t* ids, int64_t n, uint32_t* slots, hipStream_t st);
+int table_row_view(void* table, const float** rows, int* dim, int* row_floats);
+
 }  // namespace mono
 
 #endif  // MONO_COMMON_H_

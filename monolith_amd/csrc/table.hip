@@ -2159,6 +2159,52 @@ int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, con
   return 0;
 }
 
+// Slots of `ids` (kNoSlot for ids the table does not hold), nothing else touched: the resolve
+// half of the fused lookup + pool (layout.hip, mono_lookup_to_layout).
+__global__ void __launch_bounds__(256) k_resolve(TableDev t, const int64_t* __restrict__ ids, int64_t n,
+                                                 uint32_t* __restrict__ slots) {
+  const int sub = lane_sub(), gshift = lane_gshift();
+  const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
+  for (int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8) * kIlpP; i0 < n;
+       i0 += ngroups * kIlpP) {
+    const int64_t mine = i0 + sub < n ? ids[i0 + sub] : kEmpty;
+    int64_t key[kIlpP], k0[kIlpP];
+    uint64_t b[kIlpP];
+#pragma unroll
+    for (int q = 0; q < kIlpP; ++q) key[q] = __shfl(mine, q, 8);
+#pragma unroll
+    for (int q = 0; q < kIlpP; ++q) {
+      b[q] = mix64((uint64_t)key[q]) & t.bucket_mask;
+      k0[q] = t.keys[b[q] * kBucket + sub];
+    }
+    uint32_t my_slot = kNoSlot;
+#pragma unroll
+    for (int q = 0; q < kIlpP; ++q) {
+      const uint32_t sl = group_find_pre(t, key[q], b[q], k0[q], sub, gshift);
+      if (sub == q) my_slot = sl;
+    }
+    if (i0 + sub < n) slots[i0 + sub] = my_slot;
+  }
+}
+
+int table_resolve_slots(void* table, const int64_t* ids, int64_t n, uint32_t* slots, hipStream_t st) {
+  MONO_REQUIRE(table, "table_resolve_slots: null table");
+  if (n == 0) return 0;
+  Table* t = (Table*)table;
+  hipLaunchKernelGGL(k_resolve, dim3(grid_for(n, 32 * kIlpP)), dim3(256), 0, st, t->d, ids, n, slots);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int table_row_view(void* table, const float** rows, int* dim, int* row_floats) {
+  MONO_REQUIRE(table, "table_row_view: null table");
+  Table* t = (Table*)table;
+  *rows = t->d.rows;
+  *dim = t->d.dim;
+  *row_floats = t->d.row_floats;
+  return 0;
+}
+
 }  // namespace mono
 
 using namespace mono;

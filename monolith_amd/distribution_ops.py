@@ -365,3 +365,48 @@ def fused_embedding_to_layout(embeddings_list: List[torch.Tensor],
   return list(_EmbeddingToLayout.apply(meta, fid_offset.contiguous(),
                                        feature_offset.to(torch.int32).contiguous(),
                                        *embeddings_list))
+
+
+def fused_lookup_to_layout(hash_tables: List, fid_list: List[torch.Tensor],
+                           fid_list_row_split: List[torch.Tensor], fid_offset: torch.Tensor,
+                           feature_offset: torch.Tensor, nfl_offset, batch_size, variant_type: str,
+                           feature_cfgs, ps_num: int, version: int = 2) -> List[torch.Tensor]:
+  """Fused form of what PartitionedHashTable.lookup does in two steps (distributed_ps.py:889-964):
+  `hash_tables[i].lookup(fid_list[i])` for every (table, ps) list, then fused_embedding_to_layout
+  over the results. Same arguments as fused_embedding_to_layout with (hash_tables, fid_list) in
+  place of embeddings_list, same outputs bit for bit; no [n_unique, dim] tensor is materialised
+  (forward only: training keeps the two-step form, whose embeddings the backward needs)."""
+  from monolith_amd import feature_configs as fc
+  assert variant_type in {"example", "example_batch", "examplebatch", "instance"}
+  plan = fc.build_layout_plan(feature_cfgs)
+  dev = _dev(fid_offset, "fused_lookup_to_layout")
+  if len(hash_tables) != len(fid_list):
+    raise ValueError("one hash table per fid_list entry is required")
+  ids = [torch.as_tensor(f, dtype=torch.int64).to(dev).contiguous() for f in fid_list]
+
+  class _Shape:  # what split_embeddings_v2 reads of an embedding buffer
+    def __init__(self, rows, dim):
+      self.shape, self._n = (rows, dim), rows * dim
+    def numel(self):
+      return self._n
+  shapes = [_Shape(int(i.numel()), int(t.dim_size)) for i, t in zip(ids, hash_tables)]
+  bufs = _layout_buffers(plan, shapes, fid_list_row_split, ps_num, version)
+  batch = _batch(batch_size)
+  outs = [torch.empty([batch if d == -1 else d for d in shape], dtype=torch.float32, device=dev)
+          for shape in plan.out_shapes]
+  n_s = len(plan.slices)
+  slices = (type(plan.slices[0]) * max(1, n_s))(*plan.slices) if n_s else None
+  nb = len(bufs)
+  tabs = (C.c_void_p * max(1, nb))(*[hash_tables[t].table.h for (t, _, _, _) in bufs])
+  lists = (C.c_void_p * max(1, nb))(
+      *[ids[t].data_ptr() + 8 * (off // max(1, d)) for (t, off, d, _) in bufs])
+  counts = _i64s([f // max(1, d) for (_, _, d, f) in bufs])
+  nfl = torch.as_tensor(nfl_offset).cpu().to(torch.int64).tolist()
+  h_nfl = (C.c_uint32 * max(1, len(nfl)))(*[int(x) & 0xFFFFFFFF for x in nfl])
+  fo = fid_offset.contiguous()
+  fe = feature_offset.to(torch.int32).contiguous()
+  _lib.check(_lib.lib.mono_lookup_to_layout(
+      slices, n_s, tabs, lists, counts, nb, vp(fo), C.c_int64(fo.numel()), vp(fe),
+      C.c_int64(fe.numel()), h_nfl, len(nfl), C.c_int32(batch), _ptrs(outs),
+      _i64s([int(o.numel()) for o in outs]), len(outs), _lib.stream_ptr(dev)))
+  return outs

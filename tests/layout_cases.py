@@ -108,6 +108,8 @@ def make_inputs(cfgs, batch, ps_num, seed, max_fids=6, vocab=12, shared_every=2,
       "fid_offset": np.array(fid_offset, np.uint64), "feature_offset": np.array(feature_offset, np.int32),
       "nfl_offset": np.array(nfl_offset, np.uint32), "batch": batch, "ps_num": ps_num,
       "sample_fids": sample_fids, "fid_emb": fid_emb, "names": names,
+      # fid -> row of every (feature, ps), in row order; the features of every table
+      "rows": rows, "tables": tables, "table_feats": table_feats,
   }
 
 

@@ -83,3 +83,54 @@ def test_layout_v1_and_validation():
   with pytest.raises(_lib.MonolithHipError):  # two runs for a batch of three
     distribution_ops.fused_embedding_to_layout([emb], [], fid_offset, feature_offset, [0], 3,
                                                "instance", cfgs, 1, version=1)
+
+
+@pytest.mark.parametrize("dim,opt,batch,ps_num,max_fids,vocab", [
+    (16, "sgd", 257, 4, 80, 300), (16, "adagrad", 512, 2, 30, 5), (6, "adagrad", 33, 3, 12, 40),
+    (64, "adagrad", 64, 2, 20, 200)])
+def test_fused_lookup_to_layout_equals_lookup_then_layout(dim, opt, batch, ps_num, max_fids, vocab):
+  """mono_lookup_to_layout (rows gathered from the tables and pooled in one pass) against the
+  two-step form it fuses: table.lookup per (table, ps) FID list, then fused_embedding_to_layout
+  — bit for bit, including FIDs the tables do not hold (rows of zeros) and, through the two-step
+  form, against the oracle."""
+  from monolith_amd import distribution_ops, feature_configs as fc
+  from tests import hip_backend
+  cfgs = lc.make_pooling_configs(dim=dim)
+  inp = lc.make_inputs(cfgs, batch=batch, ps_num=ps_num, seed=dim + batch, max_fids=max_fids,
+                       vocab=vocab, shared_every=3)
+  plan = fc.build_layout_plan(cfgs)
+  rng = np.random.Generator(np.random.PCG64(7))
+  tables, fid_lists, embs_np = [], [], []
+  for ti, t in enumerate(inp["tables"]):
+    for ps in range(ps_num):
+      fids = [f for n in inp["table_feats"][t] for f in inp["rows"][(n, ps)]]
+      fl = np.array(fids, np.int64)
+      rows = inp["embeddings_list"][ti * ps_num + ps].reshape(-1, dim).copy()
+      assert len(rows) == len(fl)
+      tab = hip_backend.make_table({"segments": [{"dim": dim, "opt": opt}]})
+      keep = rng.random(len(fl)) > 0.1          # a tenth of the FIDs never reach the table
+      if keep.any():
+        tab.assign(fl[keep], rows[keep])
+      rows[~keep] = 0.0
+      tables.append(tab.t)
+      fid_lists.append(torch.tensor(fl, device=dev()))
+      embs_np.append(rows)
+  splits = [torch.tensor(s) for s in inp["fid_list_row_split"]]
+  fid_offset = torch.tensor(inp["fid_offset"].view(np.int64), device=dev())
+  feature_offset = torch.tensor(inp["feature_offset"], device=dev())
+  looked_up = [t.lookup(f) for t, f in zip(tables, fid_lists)]
+  for e, r in zip(looked_up, embs_np):
+    assert np.array_equal(e.cpu().numpy().reshape(-1, dim).view(np.uint32), r.view(np.uint32))
+  two_step = distribution_ops.fused_embedding_to_layout(
+      [e.reshape(-1) for e in looked_up], splits, fid_offset, feature_offset, inp["nfl_offset"],
+      inp["batch"], "example_batch", cfgs, ps_num)
+  fused = distribution_ops.fused_lookup_to_layout(
+      tables, fid_lists, splits, fid_offset, feature_offset, inp["nfl_offset"], inp["batch"],
+      "example_batch", cfgs, ps_num)
+  bufs = lc.oracle_bufs(plan, dict(inp, embeddings_list=[r.reshape(-1) for r in embs_np]))
+  exp = cpu.embedding_to_layout(plan.slices, plan.out_shapes, bufs, inp["fid_offset"],
+                                inp["feature_offset"], inp["nfl_offset"], inp["batch"])
+  assert len(fused) == len(two_step) == len(exp)
+  for i, (a, b, e) in enumerate(zip(fused, two_step, exp)):
+    assert np.array_equal(a.cpu().numpy().view(np.uint32), b.detach().cpu().numpy().view(np.uint32)), i
+    assert np.array_equal(a.cpu().numpy().view(np.uint32), e.view(np.uint32)), i
