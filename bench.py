@@ -1,15 +1,24 @@
-"""bench.py — BASELINE.json config 2 on MI355X: synthetic Criteo-shaped stream, 26 single-hot
-slots, 1e8-row table, dim 16 fp32, batch 65536, Adagrad. One step = lookup of every FID
-occurrence + apply_gradients (dedup) of one gradient row per occurrence.
+"""bench.py — the sparse-embedding hot path on MI355X, BASELINE.json's configurations.
 
-  python bench.py [--gpus N --steps K --warmup W]     (N > 1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W] [--config 2|3|4|5]
+                                                   (N > 1: launched by torch.distributed.run)
 
-metric value = (lookups + updates) / s = 2 * n * N / t_step, inputs resident in HBM.
-Multi-GPU (N > 1): the 1e8-row table is sharded by floormod(fid, N) over the ranks; every rank
-draws its own batch of 65536 samples (weak scaling) and a step is the sync-training exchange of
-distributed_ps_sync: reorder/dedup -> all-to-all(FIDs) -> fused lookup on the owner ->
-all-to-all(rows) -> gather, then gather-gradient -> all-to-all(grads) -> fused optimize (RCCL).
-`--backend gloo` rehearses that path with several ranks on ONE GPU (not a measurement).
+metric value = (lookups + updates) / s = 2 * n * N / t_step (n = FID occurrences per step per GPU),
+inputs resident in HBM when the timed region starts.
+
+  --config 2 (default at N = 1, the headline line): Criteo-shaped stream, 26 single-hot slots,
+      1e8-row table, dim 16 fp32, batch 65536, Adagrad; step = lookup + apply_gradients(dedup).
+  --config 3: 8 multi-hot slots (bags ~ Poisson(50), ids Zipf 1.1 over 1e7 per slot), batch 16384,
+      half SUM half MEAN pooling into one CONCAT layout, FTRL; step = sharding_sparse_fids
+      (dedup) -> lookup -> fused_embedding_to_layout -> its gradient -> apply_gradients.
+  --config 4 (every N > 1): dim 64 Adagrad, 1.25e8 rows PER GPU (1e9 at N = 8) sharded by
+      floormod(fid, N), batch 65536 per rank (weak scaling); step = the sync-training exchange
+      of distributed_ps_sync: reorder/dedup -> all-to-all(FIDs) -> fused lookup on the owner ->
+      all-to-all(rows) -> gather, then gather-gradient -> all-to-all(grads) -> fused optimize.
+  --config 5: config 2 + sliding hash filter (threshold 3, capacity 3e8, 7 blocks), 5 % of every
+      step's FIDs from a fresh range, req_time + 1 h per step, half the slots expire after a day,
+      evict every 24 steps.
+`--backend gloo` rehearses the exchange with several ranks on ONE GPU (not a measurement).
 """
 import argparse
 import ctypes as C
@@ -56,7 +65,7 @@ def populate(table, device, rows_per_slot_cap=None):
   return time.time() - t0
 
 
-def cpu_baseline(ids_batches, grad, lr):
+def cpu_baseline(ids_batches, grad, lr, D=16):
   """The CPU oracle ('port' of the reference algorithm, oracle/oracle.cc) on a bounded sample of
   the same stream: tables holding exactly the FIDs of the sampled batches, then lookup +
   apply_gradients(dedup). Threads own disjoint table shards (no locks: an upper bound for the
@@ -65,7 +74,7 @@ def cpu_baseline(ids_batches, grad, lr):
   threads = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "16")), os.cpu_count() or 1))
   ids_np = [b.cpu().numpy() for b in ids_batches]
   g = grad.cpu().numpy()
-  seg = cpu.seg(16, "adagrad", "uniform", init_a=-0.05, init_b=0.05)
+  seg = cpu.seg(D, "adagrad", "uniform", init_a=-0.05, init_b=0.05)
   dt, rows = cpu.bench_lookup_apply_mt([seg], ids_np, g, lr, threads)
   n = sum(len(b) for b in ids_np)
   dt1, _ = cpu.bench_lookup_apply_mt([seg], ids_np[:1], g, lr, 1)
@@ -100,11 +109,15 @@ def main_sharded(args, rank, world, device):
   os.environ["MONOLITH_SYNC_EMPTY_RANK0_PS_SHARD"] = "0"  # plain mod-N: all ranks hold rows
   from monolith_amd import distributed_ps_sync, entry, hash_table_ops, multi_type_hash_table
   global SLOT_VOCAB
-  if args.rows != 1e8:
-    scale = args.rows / 1e8
+  # config 4: dim 64, 1.25e8 rows per GPU (1e9 at N = 8); --sharded alone keeps config 2's shape
+  cfg4 = args.config == 4
+  D = args.dim or (64 if cfg4 else 16)
+  rows = args.rows if args.rows != 1e8 else (1.25e8 * world if cfg4 else 1e8)
+  if rows != 1e8:
+    scale = rows / 1e8
     SLOT_VOCAB = [max(10, int(v * scale)) for v in SLOT_VOCAB]
   total_rows = sum(SLOT_VOCAB)
-  lr, D = 0.01, 16
+  lr = 0.01
   tc = entry.EmbeddingHashTableConfig(
       segments=[entry.CombineAsSegment(D, entry.RandomUniformInitializer(-0.05, 0.05),
                                        entry.AdagradOptimizer(initial_accumulator_value=0.1))],
@@ -120,6 +133,7 @@ def main_sharded(args, rank, world, device):
   local = table._table._hash_tables["criteo"]
   # populate this rank's shard: fid = slot << 48 | r with floormod(fid, N) == rank
   chunk = 1 << 22
+  chunk = 1 << (22 if D <= 16 else 20)
   zeros = torch.zeros((chunk, D), dtype=torch.float32, device=device)
   t0 = time.time()
   for s_, v in enumerate(SLOT_VOCAB):
@@ -179,7 +193,7 @@ def main_sharded(args, rank, world, device):
   # per-GPU algorithmic HBM bytes of one step: every occurrence is gathered and
   # its gradient scattered on the requesting rank (2 * (4 + 4D) + 4D out + 4D grad), every
   # per-rank-unique FID is looked up and updated once on its owner (144 + 72 + 268 B)
-  per_gpu_bytes = n * (8 + 4 * D * 2 + 8) + uniq * n * (144 + 72 + 268)
+  per_gpu_bytes = n * (8 + 4 * D * 2 + 8) + uniq * n * ((16 + 8 * D) + (8 + 4 * D) + (12 + 16 * D))
   step_gbs = per_gpu_bytes / (ms_per_step * 1e-3) / 1e9
   # xGMI: a per-rank-unique FID moves 8 B out, 4D B back, 4D B of gradient; (N-1)/N are remote
   fabric_bytes = uniq * n * (8 + 8 * D) * (world - 1) / world
@@ -188,11 +202,11 @@ def main_sharded(args, rank, world, device):
       "unit": "lookups+updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
       "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
       "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-      "config": {"workload": "criteo-shaped: 26 single-hot slots, %.3g-row table sharded by "
-                             "floormod(fid, %d), dim 16 fp32, batch %d per GPU, Adagrad, "
+      "config": {"workload": "%scriteo-shaped: 26 single-hot slots, %.3g-row table sharded by "
+                             "floormod(fid, %d), dim %d fp32, batch %d per GPU, Adagrad, "
                              "distributed_ps_sync lookup + apply_gradients (FID / row / grad "
-                             "all-to-all, backend %s)" % (total_rows, world, args.batch,
-                                                          args.backend),
+                             "all-to-all, backend %s)" % ("config 4: " if cfg4 else "", total_rows,
+                                                          world, D, args.batch, args.backend),
                  "fids_per_step_per_gpu": n, "unique_ratio_per_rank": uniq, "skew": args.skew,
                  "parallelism": "table sharded over %d GPUs, all-to-all exchange" % world,
                  "populate_s": t_pop, "table_rows": total_rows},
@@ -202,11 +216,325 @@ def main_sharded(args, rank, world, device):
                    "xgmi_GBps_per_gpu": fabric_bytes / (ms_per_step * 1e-3) / 1e9},
       "cpu_baseline": None,
   }
+  if rank == 0 and world == 1 and not args.no_cpu:
+    res["cpu_baseline"] = cpu_baseline(pool[:2], grad, lr, D)
   if rank == 0:
     emit(res)
   if dist.is_initialized():
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _timed_steps(step, args, sync):
+  for i in range(args.warmup):
+    step(i)
+  sync()
+  t0 = time.perf_counter()
+  for i in range(args.steps):
+    step(args.warmup + i)
+  sync()
+  return (time.perf_counter() - t0) / args.steps
+
+
+def _phase_ms(phases, reps=6):
+  """Average milliseconds of every (name, fn) phase, run in order `reps` times, timed with HIP
+  events on the current stream (the stream every kernel of these phases is launched on, or
+  joined to before the phase returns)."""
+  ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(phases) + 1)] for _ in range(reps)]
+  for r in range(reps):
+    ev[r][0].record()
+    for k, (_, fn) in enumerate(phases):
+      fn()
+      ev[r][k + 1].record()
+  torch.cuda.synchronize()
+  out = {}
+  for k, (name, _) in enumerate(phases):
+    out[name] = float(np.mean([ev[r][k].elapsed_time(ev[r][k + 1]) for r in range(2, reps)]))
+  return out
+
+
+def main_config3(args, device):
+  """BASELINE config 3: multi-hot slots, sum / mean pooling into a layout, FTRL."""
+  from monolith_amd import distribution_ops, entry, feature_configs as fc, hash_table_ops, parsers
+  from monolith_amd.embedding_combiners import Ragged
+  S, D, B, lr = 8, 16, args.batch if args.batch != 65536 else 16384, 0.01
+  vocab = int(1e7 * (args.rows / 1e8)) if args.rows != 1e8 else 10_000_000
+  cfgs = fc.FeatureConfigs()
+  concat = fc.OutConfig()
+  names = ["slot_%02d" % s_ for s_ in range(S)]
+  for s_, name in enumerate(names):
+    pool = fc.PoolingType.SUM if s_ % 2 == 0 else fc.PoolingType.MEAN
+    cfgs.feature_configs[name] = fc.FeatureConfig("t0", [D], pool, 0)
+    concat.slice_configs.append(fc.SliceConfig(name, 0, D))
+  fc.infer_shape(concat, fc.OutType.CONCAT)
+  cfgs.out_configs = {"concat": concat}
+  tc = entry.EmbeddingHashTableConfig(
+      segments=[entry.CombineAsSegment(D, entry.RandomUniformInitializer(-0.05, 0.05),
+                                       entry.FtrlOptimizer(initial_accumulator_value=0.1, beta=1.0))],
+      initial_capacity=int(S * vocab * 1.02), seed=77)
+  table = hash_table_ops.hash_table_from_config(entry.HashTableConfigInstance(tc, [lr]),
+                                                name_suffix="bench_c3")
+  chunk = 1 << 22
+  zeros = torch.zeros((chunk, D), dtype=torch.float32, device=device)
+  t0 = time.time()
+  for s_ in range(S):
+    for lo in range(0, vocab, chunk):
+      m = min(chunk, vocab - lo)
+      ids = torch.arange(lo, lo + m, device=device, dtype=torch.int64) | ((s_ + 1) << 48)
+      table.assign_add(ids, zeros[:m], req_time=1)
+  torch.cuda.synchronize()
+  t_pop = time.time() - t0
+  assert table.size() == S * vocab
+
+  gen = torch.Generator(device=device)
+  gen.manual_seed(20250117)
+
+  def make_batch():
+    feats = {}
+    for s_, name in enumerate(names):
+      lens = torch.poisson(torch.full((B,), 50.0, device=device), generator=gen).clamp_(1, 200).to(torch.int64)
+      rs = torch.zeros(B + 1, dtype=torch.int64, device=device)
+      rs[1:] = torch.cumsum(lens, 0)
+      tot = int(rs[-1].item())
+      u = torch.rand(tot, generator=gen, device=device, dtype=torch.float64)
+      # Zipf(1.1) over [1, vocab]: inverse of the truncated continuous power-law CDF
+      a = 1.0 - 1.1
+      r = ((float(vocab) ** a - 1.0) * u + 1.0).pow(1.0 / a).to(torch.int64).clamp_(1, vocab) - 1
+      feats[name] = Ragged(r | ((s_ + 1) << 48), rs)
+    return feats
+
+  n_pool = 4
+  pool = [make_batch() for _ in range(n_pool)]
+  n = int(np.mean([sum(f.values.numel() for f in b.values()) for b in pool]))
+  gout = torch.randn((B, S * D), generator=gen, device=device, dtype=torch.float32) * 0.1
+  st = {}
+
+  def p_shard(i):
+    st["sh"] = parsers.sharding_sparse_fids(pool[i % n_pool], 1, cfgs, True, fid_list_ret_list=True)
+
+  def p_lookup():
+    fid_list = st["sh"][0]
+    st["emb"] = table.lookup(fid_list[0])
+
+  def p_layout():
+    fid_list, fid_offset, feature_offset, nfl, batch, splits = st["sh"]
+    st["out"] = distribution_ops.fused_embedding_to_layout(
+        [st["emb"].reshape(-1)], splits, fid_offset, feature_offset, nfl, batch, "example_batch",
+        cfgs, 1)
+
+  def p_fused():
+    fid_list, fid_offset, feature_offset, nfl, batch, splits = st["sh"]
+    st["out2"] = distribution_ops.fused_lookup_to_layout(
+        [table], fid_list, splits, fid_offset, feature_offset, nfl, batch, "example_batch", cfgs, 1)
+
+  def p_grad():
+    fid_list, fid_offset, feature_offset, nfl, batch, splits = st["sh"]
+    st["g"] = distribution_ops.fused_embedding_to_layout_grad(
+        nfl, feature_offset, fid_offset, batch, [st["emb"].reshape(-1)], splits, [gout],
+        "example_batch", cfgs, 1)
+
+  def p_apply(i):
+    nonlocal table
+    fid_list = st["sh"][0]
+    table = table.apply_gradients(fid_list[0], st["g"][0].reshape(-1, D), global_step=i,
+                                  req_time=10 + i)
+
+  def step(i):
+    p_shard(i); p_lookup(); p_layout(); p_grad(); p_apply(i)
+
+  dt = _timed_steps(step, args, torch.cuda.synchronize)
+  u_per_step = float(np.mean([torch.cat([torch.unique(f.values) for f in b.values()]).numel()
+                              for b in pool]))
+  ph = _phase_ms([("sharding_sparse_fids", lambda: p_shard(0)), ("lookup", p_lookup),
+                  ("layout_forward", p_layout), ("fused_lookup_to_layout", p_fused),
+                  ("layout_grad", p_grad), ("apply_gradients", lambda: p_apply(999))])
+  same = all(torch.equal(a, b) for a, b in zip(st["out"], st["out2"]))
+  # algorithmic bytes (SURVEY.md 8d): pooled lookup per occurrence 8 (descriptor) + 4D (row read)
+  # + 4D / L (pooled output); per unique FID the lookup moves 8 + 8 + 4D + 4D; the gradient
+  # scatter reads 4D per occurrence and writes 4D per unique; FTRL update 8 + 8 + 4D + 2*12D + 4
+  u = u_per_step
+  alg = {
+      "sharding_sparse_fids": n * (8 + 8) + u * 8,
+      "lookup": u * (16 + 8 * D),
+      "layout_forward": n * (8 + 4 * D) + B * S * D * 4,
+      "fused_lookup_to_layout": u * 20 + n * (8 + 4 + 4 * D) + B * S * D * 4,
+      "layout_grad": n * (8 + 4 * D) + u * 4 * D,
+      "apply_gradients": u * (8 + 4 * D) + u * (8 + 2 * 12 * D + 4),
+  }
+  step_alg = sum(alg[k] for k in alg if k != "fused_lookup_to_layout")
+  dom = max((k for k in ph if k != "fused_lookup_to_layout"), key=lambda k: ph[k])
+  achieved = alg[dom] / (ph[dom] * 1e-3) / 1e9
+  res = {
+      "metric": "FID lookups+updates/sec (node)", "value": 2.0 * n / dt,
+      "unit": "lookups+updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "dtype": "f32", "data": "synthetic",
+      "config": {"workload": "config 3: %d multi-hot slots, bags ~ Poisson(50) in [1, 200], ids "
+                             "Zipf(1.1) over %.3g per slot, batch %d, half SUM half MEAN pooling "
+                             "into a CONCAT layout, dim %d, FTRL; sharding_sparse_fids -> lookup -> "
+                             "fused_embedding_to_layout -> gradient -> apply_gradients" %
+                             (S, vocab, B, D),
+                 "fids_per_step": n, "unique_fids_per_step": u, "table_rows": S * vocab,
+                 "populate_s": t_pop, "fused_forward_equals_two_step": bool(same)},
+      "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                   "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                   "algorithmic_bytes": alg[dom], "phase_ms": ph,
+                   "phase_algorithmic_GBps": {k: alg[k] / (ph[k] * 1e-3) / 1e9 for k in ph},
+                   "phase_note": "phases timed with HIP events on the launch stream outside the "
+                                 "timed region; fused_lookup_to_layout = the one-pass alternative "
+                                 "to lookup + layout_forward (not part of the step)",
+                   "step_algorithmic_GBps": step_alg / dt / 1e9,
+                   "step_frac": step_alg / dt / 1e9 / HBM_PEAK_GBS},
+      "cpu_baseline": None,
+  }
+  if not args.no_cpu:
+    res["cpu_baseline"] = cpu_baseline_config3(pool[0], cfgs, names, D, lr, B)
+  emit(res)
+
+
+def cpu_baseline_config3(batch, cfgs, names, D, lr, B, sample=384):
+  """The oracle ('port') on the first `sample` samples of one batch: per-feature dedup, table
+  lookup, pooling into the layout, its gradient, FTRL update. One thread."""
+  from monolith_amd import feature_configs as fc
+  from oracle import cpu
+  plan = fc.build_layout_plan(cfgs)
+  fid_offset, feature_offset, nfl_offset, uniq = [], [], [], []
+  n_occ = 0
+  for fi, name in enumerate(names):
+    rs = batch[name].row_splits[:sample + 1].cpu().numpy()
+    vals = batch[name].values[:int(rs[-1])].cpu().numpy()
+    n_occ += len(vals)
+    nfl_offset.append(len(feature_offset))
+    u, inv = np.unique(vals, return_inverse=True)
+    first = np.full(len(u), len(vals), np.int64)
+    np.minimum.at(first, inv, np.arange(len(vals)))
+    order = np.argsort(first, kind="stable")       # first-occurrence order
+    rank = np.empty(len(u), np.int64)
+    rank[order] = np.arange(len(u))
+    uniq.append(u[order])
+    feature_offset += rs[:-1].tolist()
+    base = len(fid_offset)
+    feature_offset[-sample:] = [base + int(x) for x in rs[:-1]]
+    fid_offset += ((fi << 32) | rank[inv]).tolist()
+  fid_offset = np.array(fid_offset, np.uint64)
+  feature_offset = np.array(feature_offset, np.int32)
+  nfl_offset = np.array(nfl_offset, np.uint32)
+  ids = np.concatenate(uniq)
+  seg = cpu.seg(D, "ftrl", "uniform", init_acc=0.1, beta=1.0, init_a=-0.05, init_b=0.05)
+  t = cpu.OracleTable([seg], initial_capacity=len(ids) * 2)
+  t.assign_add(ids, np.zeros((len(ids), D), np.float32), req_time=1)
+  gout = [np.random.default_rng(0).normal(0, 0.1, (sample, len(names) * D)).astype(np.float32)]
+  t0 = time.perf_counter()
+  reps = 0
+  while time.perf_counter() - t0 < 8.0 or reps < 2:
+    emb = t.lookup(ids)
+    bufs, pos = [], 0
+    for u in uniq:
+      bufs.append((emb[pos:pos + len(u)].reshape(-1), D))
+      pos += len(u)
+    cpu.embedding_to_layout(plan.slices, plan.out_shapes, bufs, fid_offset, feature_offset,
+                            nfl_offset, sample)
+    g = cpu.embedding_to_layout_grad(plan.slices, plan.slice_idx_of, plan.max_slice_num,
+                                     [(len(a), d) for a, d in bufs], fid_offset, feature_offset,
+                                     nfl_offset, sample, gout)
+    t.apply_gradients(ids, np.concatenate(g).reshape(-1, D), [lr], req_time=5 + reps)
+    reps += 1
+  dt = (time.perf_counter() - t0) / reps
+  return {"value": 2.0 * n_occ / dt, "unit": "lookups+updates/s", "cores": 1, "kind": "port",
+          "sample": "the first %d samples of one batch (%d FID occurrences, %d unique), tables "
+                    "holding only those FIDs; lookup + pooling + gradient + FTRL update, dedup "
+                    "excluded, %d repetitions" % (sample, n_occ, len(ids), reps)}
+
+
+def main_config5(args, device):
+  """BASELINE config 5: config 2's stream with a sliding hash filter in front of inserts, 5 % of
+  every step's FIDs from a fresh range, expiry eviction every 24 steps."""
+  from monolith_amd import _lib, entry, hash_filter_ops, hash_table_ops
+  global SLOT_VOCAB
+  if args.rows != 1e8:
+    scale = args.rows / 1e8
+    SLOT_VOCAB = [max(10, int(v * scale)) for v in SLOT_VOCAB]
+  total_rows = sum(SLOT_VOCAB)
+  lr, D = 0.01, 16
+  tc = entry.EmbeddingHashTableConfig(
+      segments=[entry.CombineAsSegment(D, entry.RandomUniformInitializer(-0.05, 0.05),
+                                       entry.AdagradOptimizer(initial_accumulator_value=0.1))],
+      initial_capacity=int(total_rows * 1.15), seed=1234)
+  tc.slot_expire_time_config.default_expire_time = 36500
+  tc.slot_expire_time_config.slot_expire_times = {s_: 1 for s_ in range(0, len(SLOT_VOCAB), 2)}
+  thr = entry.SlotOccurrenceThresholdConfig(default_occurrence_threshold=3)
+  filt = hash_filter_ops.create_hash_filters(0, True, thr, filter_capacity=300_000_000)[0]
+  now0 = 1_700_000_000
+  # populated WITHOUT the filter (a trained table), then the filter is attached
+  table = hash_table_ops.hash_table_from_config(entry.HashTableConfigInstance(tc, [lr]),
+                                                hash_filter=filt, name_suffix="bench_c5")
+  chunk = 1 << 22
+  zeros = torch.zeros((chunk, D), dtype=torch.float32, device=device)
+  t0 = time.time()
+  for s_, v in enumerate(SLOT_VOCAB):
+    for lo in range(0, v, chunk):
+      m = min(chunk, v - lo)
+      ids = torch.arange(lo, lo + m, device=device, dtype=torch.int64) | (s_ << 48)
+      _lib.check(_lib.lib.mono_table_assign_add(table.table.h, None, _lib.vp(ids), _lib.vp(zeros),
+                                                C.c_int64(m), C.c_int64(now0),
+                                                _lib.stream_ptr(device)))
+  torch.cuda.synchronize()
+  t_pop = time.time() - t0
+  rows0 = table.size()
+
+  gen = torch.Generator(device=device)
+  gen.manual_seed(20250117)
+  n_pool = 8
+  pool = [make_batch(gen, args.batch, device, args.skew) for _ in range(n_pool)]
+  n = pool[0].numel()
+  grad = torch.randn((n, D), generator=gen, device=device, dtype=torch.float32) * 0.1
+  n_fresh = n // 20
+  fresh_pos = torch.randperm(n, generator=gen, device=device)[:n_fresh]
+  fresh_slot = (fresh_pos % len(SLOT_VOCAB)) << 48
+  state = {"t": table, "fresh": 1 << 40, "evictions": 0}
+
+  def step(i):
+    ids = pool[i % n_pool].clone()
+    # 5 % churn: ids nobody has seen (each occurs once this step; the filter counts them)
+    ids[fresh_pos] = fresh_slot | (state["fresh"] + torch.arange(n_fresh, device=device))
+    state["fresh"] += n_fresh // 3  # two thirds of a step's fresh ids come back in later steps
+    now = now0 + 3600 * (i + 1)
+    t = state["t"]
+    t.lookup(ids)
+    state["t"] = t.apply_gradients(ids, grad, global_step=i, enable_dedup=True, req_time=now)
+    if i % 24 == 23:
+      state["t"].evict(now)
+      state["evictions"] += 1
+
+  dt = _timed_steps(step, args, torch.cuda.synchronize)
+  rows1 = state["t"].size()
+  uniq = float(np.mean([torch.unique(b).numel() / n for b in pool]))
+  i0 = args.warmup + args.steps
+  ph = _phase_ms([("make_ids", lambda: None), ("step", lambda: step(i0))], reps=8)
+  step_bytes = n * 144 + n * (8 + 4 * D) + uniq * n * (8 + 2 * (8 * D) + 4) + n_fresh * 4
+  res = {
+      "metric": "FID lookups+updates/sec (node)", "value": 2.0 * n / dt,
+      "unit": "lookups+updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "dtype": "f32", "data": "synthetic",
+      "config": {"workload": "config 5: criteo-shaped stream (26 slots, %.3g rows, dim 16, Adagrad, "
+                             "batch %d) + sliding hash filter (threshold 3, capacity 3e8, 7 blocks) "
+                             "gating inserts, 5 %% fresh FIDs per step, req_time + 1 h per step, "
+                             "every second slot expires after 1 day, evict every 24 steps" %
+                             (total_rows, args.batch),
+                 "fids_per_step": n, "unique_ratio": uniq, "fresh_fids_per_step": n_fresh,
+                 "rows_before": rows0, "rows_after": rows1, "evictions": state["evictions"],
+                 "filter_state": {k: v for k, v in filt.state().items() if k != "num_elements"},
+                 "populate_s": t_pop},
+      "roofline": {"bound": "hbm", "kernel": "whole step (lookup + gated apply_gradients)",
+                   "achieved": step_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": step_bytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                   "algorithmic_bytes": step_bytes, "phase_ms": ph,
+                   "step_algorithmic_GBps": step_bytes / dt / 1e9,
+                   "step_frac": step_bytes / dt / 1e9 / HBM_PEAK_GBS},
+      "cpu_baseline": None,
+  }
+  emit(res)
 
 
 def main():
@@ -221,7 +549,11 @@ def main():
   ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (single-GPU rehearsal)")
   ap.add_argument("--sharded", action="store_true",
                   help="run the N > 1 exchange pipeline even at N = 1 (profiling aid)")
+  ap.add_argument("--config", type=int, default=0, help="2 | 3 | 4 | 5 (default: 2, or 4 when N > 1)")
+  ap.add_argument("--dim", type=int, default=0, help="config 4 / --sharded: row width (default 64 / 16)")
   args = ap.parse_args()
+  if args.config == 0:
+    args.config = 4 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 2
   quiet_stdout()
 
   rank = int(os.environ.get("RANK", "0"))
@@ -243,8 +575,12 @@ def main():
     else:
       dist.init_process_group("gloo")
     return main_sharded(args, rank, world, device)
-  if args.sharded:
+  if args.sharded or args.config == 4:
     return main_sharded(args, rank, world, device)
+  if args.config == 3:
+    return main_config3(args, device)
+  if args.config == 5:
+    return main_config5(args, device)
 
   from monolith_amd import _lib, entry, hash_table_ops
   global SLOT_VOCAB

@@ -571,7 +571,8 @@ int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slice
   MONO_TRY(build_plan(h_slices, n_slices, h_emb_grads, h_emb_dims, h_emb_floats, n_bufs,
                       h_nfl_offset, n_nfl, n_features, batch, n_outs, h_out_floats, &hp,
                       "mono_embedding_to_layout_grad"));
-  MONO_TRY(finish_plan(&hp, batch, "mono_embedding_to_layout_grad"));
+  MONO_TRY(finish_plan(&hp, batch, "mono_embedding_to_layout_grad",
+                       const_cast<float* const*>(h_out_grads)));
   long long total_floats = 0;
   for (int i = 0; i < n_bufs; ++i) {
     if (h_emb_floats[i] > 0)
@@ -610,11 +611,19 @@ int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slice
   MONO_REQUIRE(nc < (long long)0xFFFFFFF0ll, "mono_embedding_to_layout_grad: too many uses");
   const size_t n_al = ((size_t)nc + 63) & ~(size_t)63;
   const size_t b_gs = al256((size_t)n_slices * sizeof(GradSliceDev));
-  const size_t extra = b_gs + 4 * n_al * sizeof(uint32_t) + n_al * sizeof(void*) + 1024;
+  const size_t b_dims = al256((size_t)n_slices * sizeof(int32_t));
+  const size_t extra = b_gs + b_dims + 4 * n_al * sizeof(uint32_t) + n_al * sizeof(void*) + 1024;
   DevPlan dp;
   MONO_TRY(upload_plan(hp, (const void* const*)h_out_grads, n_outs, extra, &dp, st));
   char* p = dp.rest;
   GradSliceDev* d_gs = (GradSliceDev*)p; p += b_gs;
+  int32_t* d_dims = (int32_t*)p; p += b_dims;
+  {
+    std::vector<int32_t> h_dims(n_slices);
+    for (int i = 0; i < n_slices; ++i) h_dims[i] = hp.slices[i].dim;
+    MONO_HIP(hipMemcpyAsync(d_dims, h_dims.data(), (size_t)n_slices * sizeof(int32_t),
+                            hipMemcpyHostToDevice, st));
+  }
   const float** srcp = (const float**)p; p += al256(n_al * sizeof(void*));
   uint32_t* key = (uint32_t*)p; p += n_al * sizeof(uint32_t);
   uint32_t* cslice = (uint32_t*)p; p += n_al * sizeof(uint32_t);
@@ -639,9 +648,29 @@ int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slice
   const size_t tmp = sort_pairs_tmp_bytes((size_t)nc, end_bit);
   MONO_TRY(g_lws_sort.ensure(tmp));
   MONO_TRY(sort_pairs_u32(key, skey, nullptr, sidx, (size_t)nc, end_bit, g_lws_sort.ptr, tmp, st));
-  hipLaunchKernelGGL(k_layout_grad_apply, dim3((unsigned)((nc + 31) / 32)), dim3(256), 0, st, a,
-                     skey, sidx);
-  MONO_HIP(hipGetLastError());
+  // Every destination's uses are now one run of the sorted keys, in the reference's order: summed
+  // by the table's segment machinery (sub-group walk, long-segment kernel, chunk combine), one
+  // pass per distinct slice width. (One sub-group walking a run on its own took 64 ms for a
+  // config-3 batch: a Zipf head is hundreds of thousands of uses of one FID.) The result is built
+  // in one contiguous scratch image of all buffers and copied out.
+  static Workspace grad_img;
+  MONO_TRY(grad_img.ensure((size_t)total_floats * sizeof(float) + 256));
+  float* img = (float*)grad_img.ptr;
+  MONO_HIP(hipMemsetAsync(img, 0, (size_t)total_floats * sizeof(float), st));
+  std::vector<int> widths;
+  for (int i = 0; i < n_slices; ++i)
+    if (std::find(widths.begin(), widths.end(), hp.slices[i].dim) == widths.end())
+      widths.push_back(hp.slices[i].dim);
+  for (int w : widths)
+    MONO_TRY(segment_set_sum_rows(skey, sidx, nc, srcp, cslice, d_dims, w, hp.vec == 4,
+                                  (uint32_t)total_floats, img, st));
+  long long gb = 0;
+  for (int i = 0; i < n_bufs; ++i) {
+    if (h_emb_floats[i] > 0)
+      MONO_HIP(hipMemcpyAsync(h_emb_grads[i], img + gb, (size_t)h_emb_floats[i] * sizeof(float),
+                              hipMemcpyDeviceToDevice, st));
+    gb += h_emb_floats[i];
+  }
   return 0;
 }
 

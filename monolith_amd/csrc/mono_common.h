@@ -94,6 +94,13 @@ int sort_error_report(uint32_t h_word);
 int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, const float* src,
                      int D, bool aligned4, float* out, hipStream_t st);
 
+// table.hip: out[skeys[p] .. + D) = src_ptrs[sidx[p]] of the segment's first occurrence + the later
+// ones in input order, for the segments whose occurrences belong to a class of width D
+// (cls[occurrence] -> cls_dim[class]); keys equal to skip_key are ignored.
+int segment_set_sum_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n,
+                         const float* const* src_ptrs, const uint32_t* cls, const int32_t* cls_dim,
+                         int D, bool aligned4, uint32_t skip_key, float* out, hipStream_t st);
+
 // table.hip, for the fused lookup + pool of layout.hip: the slot of every id (0xFFFFFFFF = not in
 // the table), and where the rows of a table live (weights first: columns [0, dim) of a row of
 // row_floats floats). The view is valid until the next call that can grow the table.

@@ -38,7 +38,10 @@ constexpr int kMaxSeg = 8;
 constexpr double kMaxLoad = 0.6;    // rehash when live + tombstones would exceed this
 constexpr double kGrowTarget = 0.3;  // load right after a rehash
 
-enum { MODE_ASSIGN = 0, MODE_ASSIGN_ADD = 1, MODE_OPT_SEQ = 2, MODE_OPT_DEDUP = 3, MODE_IMPORT = 4 };
+enum { MODE_ASSIGN = 0, MODE_ASSIGN_ADD = 1, MODE_OPT_SEQ = 2, MODE_OPT_DEDUP = 3, MODE_IMPORT = 4,
+       // stateless segment op: row = first occurrence, + the others in input order ("first touch
+       // copies", fused_embedding_to_layout.cc:385-400); no optimizer, no row read
+       MODE_SET_SUM = 5 };
 enum { OPTK_SGD = 0, OPTK_ADAGRAD = 1, OPTK_FTRL = 2, OPTK_MULTI = 3 };
 
 struct SegDev {
@@ -613,7 +616,19 @@ struct ApplyArgs {
   const uint32_t* nheads;
   const uint32_t* sort_err;  // sort.hip's sticky error word: non-zero = the sorted arrays are not
                              // to be trusted, the batch is skipped (k_classify emits nothing)
+  // stateless segment ops (layout gradient): source row of occurrence i = src_ptrs[i] (dim
+  // floats) instead of src + i * dim; k_classify keeps only the segments whose occurrences belong
+  // to a class of width want_dim (class of occurrence i = cls[i], width = cls_dim[class])
+  const float* const* src_ptrs;
+  int src_aligned4;
+  const uint32_t* cls;
+  const int32_t* cls_dim;
+  int want_dim;      // 0 = every segment
+  uint32_t skip_slot;  // sorted key that marks "no destination" (besides kNoSlot)
 };
+__device__ __forceinline__ const float* src_row(const ApplyArgs& a, uint32_t idx, int D) {
+  return a.src_ptrs ? a.src_ptrs[idx] : a.src + (uint64_t)idx * D;
+}
 
 // A key with many occurrences in one batch (a Zipf head): handed to a whole workgroup.
 struct LongSeg {
@@ -938,7 +953,8 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
   }
 
   if (end - first > kLongSeg && D <= kLongMaxDim && !t.serving && !t.any_sr &&
-      (mode == MODE_ASSIGN_ADD || mode == MODE_OPT_SEQ || mode == MODE_OPT_DEDUP)) {
+      (mode == MODE_ASSIGN_ADD || mode == MODE_OPT_SEQ || mode == MODE_OPT_DEDUP ||
+       mode == MODE_SET_SUM)) {
     if (sub == 0) enqueue_long(a, first, end, key, slot, fresh ? 1u : 0u);
     return;
   }
@@ -993,8 +1009,11 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       for (int q = 0; q < V; ++q)
         if (t.seg[segi[q]].sr_post) ox[q].gstep = 0;
     }
-    const bool need_state = mode >= MODE_OPT_SEQ;
-    if (fresh) {
+    const bool need_state = mode == MODE_OPT_SEQ || mode == MODE_OPT_DEDUP;
+    if (mode == MODE_SET_SUM) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) w[q] = s0[q] = s1[q] = 0.f;
+    } else if (fresh) {
 #pragma unroll
       for (int q = 0; q < V; ++q) {
         w[q] = row_init_value(t, key, e0 + q);
@@ -1021,7 +1040,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
     }
     // --- walk the occurrences in input order
     if (mode == MODE_ASSIGN) {
-      vload<V>(w, a.src + (uint64_t)a.sidx[end - 1] * D + e0);
+      vload<V>(w, src_row(a, a.sidx[end - 1], D) + e0);
       if (OPTK == OPTK_MULTI && t.serving) {
 #pragma unroll
         for (int q = 0; q < V; ++q) w[q] = comp_q(t.seg[segi[q]], w[q]);
@@ -1033,17 +1052,17 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
         // time makes a 96-occurrence segment a ~150 us chain of memory round trips)
         for (; p + 4 <= end; p += 4) {
           float g0[V], g1[V], g2[V], g3[V];
-          vload<V>(g0, a.src + (uint64_t)a.sidx[p] * D + e0);
-          vload<V>(g1, a.src + (uint64_t)a.sidx[p + 1] * D + e0);
-          vload<V>(g2, a.src + (uint64_t)a.sidx[p + 2] * D + e0);
-          vload<V>(g3, a.src + (uint64_t)a.sidx[p + 3] * D + e0);
+          vload<V>(g0, src_row(a, a.sidx[p], D) + e0);
+          vload<V>(g1, src_row(a, a.sidx[p + 1], D) + e0);
+          vload<V>(g2, src_row(a, a.sidx[p + 2], D) + e0);
+          vload<V>(g3, src_row(a, a.sidx[p + 3], D) + e0);
 #pragma unroll
           for (int q = 0; q < V; ++q) w[q] = (((w[q] + g0[q]) + g1[q]) + g2[q]) + g3[q];
         }
       }
       for (; p < end; ++p) {
         float g[V];
-        vload<V>(g, a.src + (uint64_t)a.sidx[p] * D + e0);
+        vload<V>(g, src_row(a, a.sidx[p], D) + e0);
 #pragma unroll
         for (int q = 0; q < V; ++q) w[q] += g[q];
         if (OPTK == OPTK_MULTI && t.serving) {  // every AssignAdd re-encodes (entry_accessor.cc:70-77)
@@ -1067,10 +1086,10 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       for (; p + 4 <= end; p += 4) {  // the steps depend on each other, the row loads do not
         const uint32_t i0 = a.sidx[p], i1 = a.sidx[p + 1], i2 = a.sidx[p + 2], i3 = a.sidx[p + 3];
         float g0[V], g1[V], g2[V], g3[V];
-        vload<V>(g0, a.src + (uint64_t)i0 * D + e0);
-        vload<V>(g1, a.src + (uint64_t)i1 * D + e0);
-        vload<V>(g2, a.src + (uint64_t)i2 * D + e0);
-        vload<V>(g3, a.src + (uint64_t)i3 * D + e0);
+        vload<V>(g0, src_row(a, i0, D) + e0);
+        vload<V>(g1, src_row(a, i1, D) + e0);
+        vload<V>(g2, src_row(a, i2, D) + e0);
+        vload<V>(g3, src_row(a, i3, D) + e0);
         step_one(g0, i0);
         step_one(g1, i1);
         step_one(g2, i2);
@@ -1079,29 +1098,33 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       for (; p < end; ++p) {
         float g[V];
         const uint32_t i0 = a.sidx[p];
-        vload<V>(g, a.src + (uint64_t)i0 * D + e0);
+        vload<V>(g, src_row(a, i0, D) + e0);
         step_one(g, i0);
       }
     } else {  // MODE_OPT_DEDUP: in-order sum (bridge :251-266), then one step
       float acc[V];
-      vload<V>(acc, a.src + (uint64_t)(first == j ? idx0 : a.sidx[first]) * D + e0);
+      vload<V>(acc, src_row(a, first == j ? idx0 : a.sidx[first], D) + e0);
       int64_t p = first + 1;
       for (; p + 4 <= end; p += 4) {  // 4 independent loads in flight, adds stay in order
         float g0[V], g1[V], g2[V], g3[V];
-        vload<V>(g0, a.src + (uint64_t)a.sidx[p] * D + e0);
-        vload<V>(g1, a.src + (uint64_t)a.sidx[p + 1] * D + e0);
-        vload<V>(g2, a.src + (uint64_t)a.sidx[p + 2] * D + e0);
-        vload<V>(g3, a.src + (uint64_t)a.sidx[p + 3] * D + e0);
+        vload<V>(g0, src_row(a, a.sidx[p], D) + e0);
+        vload<V>(g1, src_row(a, a.sidx[p + 1], D) + e0);
+        vload<V>(g2, src_row(a, a.sidx[p + 2], D) + e0);
+        vload<V>(g3, src_row(a, a.sidx[p + 3], D) + e0);
 #pragma unroll
         for (int q = 0; q < V; ++q) acc[q] = (((acc[q] + g0[q]) + g1[q]) + g2[q]) + g3[q];
       }
       for (; p < end; ++p) {
         float g[V];
-        vload<V>(g, a.src + (uint64_t)a.sidx[p] * D + e0);
+        vload<V>(g, src_row(a, a.sidx[p], D) + e0);
 #pragma unroll
         for (int q = 0; q < V; ++q) acc[q] = acc[q] + g[q];
       }
       const uint32_t pos0 = first == j ? idx0 : a.sidx[first];
+      if (mode == MODE_SET_SUM) {
+#pragma unroll
+        for (int q = 0; q < V; ++q) w[q] = acc[q];
+      } else
 #pragma unroll
       for (int q = 0; q < V; ++q) {
         const SegDev& sg = t.seg[segi[q]];
@@ -1164,7 +1187,9 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
       idxv[k] = a.sidx[j];
       const uint32_t prev = j > 0 ? sk[j - 1] : ~slot;
       const uint32_t next = j + 1 < n ? sk[j + 1] : ~slot;
-      if (prev != slot && slot != kNoSlot) {
+      bool keep = prev != slot && slot != kNoSlot && slot != a.skip_slot;
+      if (keep && a.want_dim) keep = a.cls_dim[a.cls[idxv[k]]] == a.want_dim;
+      if (keep) {
         if (next == slot) len[k] = (uint32_t)(segment_end<uint32_t>(sk, j, n, slot) - j);
         if (allow_long && len[k] > (uint32_t)kLongSeg)
           enqueue_long(a, j, j + len[k], 0, slot, 0u);
@@ -1215,7 +1240,9 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
   const int tid = threadIdx.x;
   const bool loader = tid >= 64;
   const int lt = tid - 64;  // loader thread index
-  const bool vec4 = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(a.src) & 15) == 0;
+  const bool vec4 = (D & 3) == 0 && (a.src_ptrs ? a.src_aligned4 != 0
+                                                : (reinterpret_cast<uintptr_t>(a.src) & 15) == 0);
+  constexpr bool kSums = MODE == MODE_OPT_DEDUP || MODE == MODE_SET_SUM;
   const uint32_t nq = *a.qcount;
   // The consumer wave is a lone dependent chain; when this kernel shares CUs with k_apply its
   // issue slots must not be arbitrated away, so it runs at raised wave priority.
@@ -1252,9 +1279,9 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
       OptX ox;
       ox.gstep = a.global_step;
       bool have_acc = false;
-      const bool need_state = MODE >= MODE_OPT_SEQ;
+      const bool need_state = MODE == MODE_OPT_SEQ || MODE == MODE_OPT_DEDUP;
       const bool part = ls.part != kNoPart;  // one chunk of a split key: emit the chunk sum only
-      if (owner && !part) {
+      if (owner && !part && MODE != MODE_SET_SUM) {
         if (ls.fresh) {
           w = row_init_value(t, ls.key, e);
           s0 = opt_nstate(kind) >= 1 ? row_init_value(t, ls.key, st0) : 0.f;
@@ -1286,7 +1313,7 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         if (vec4) {
 #pragma unroll
           for (int k = 0; k < kLStage4; ++k) {
-            S[k] = (r < rows) ? *reinterpret_cast<const float4*>(a.src + (uint64_t)ix[r] * D + eb + 4 * c)
+            S[k] = (r < rows) ? *reinterpret_cast<const float4*>(src_row(a, ix[r], D) + eb + 4 * c)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
             r += dr;
             c += dc;
@@ -1296,7 +1323,7 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
           float* Sf = reinterpret_cast<float*>(&S[0]);
 #pragma unroll
           for (int k = 0; k < 4 * kLStage4; ++k) {
-            Sf[k] = (r < rows) ? a.src[(uint64_t)ix[r] * D + eb + c] : 0.f;
+            Sf[k] = (r < rows) ? src_row(a, ix[r], D)[eb + c] : 0.f;
             r += dr;
             c += dc;
             if (c >= cpr) { c -= cpr; ++r; }
@@ -1335,7 +1362,7 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         const int rows = (int)min((int64_t)rpt, ls.end - (ls.first + tl * rpt));
         const float* tp = &tile[buf][tid];
         int r = 0;
-        if (MODE == MODE_OPT_DEDUP && !have_acc) {  // first row seeds the sum
+        if (kSums && !have_acc) {  // first row seeds the sum
           acc = tp[0];
           have_acc = true;
           r = 1;
@@ -1390,8 +1417,9 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         a.partials[(uint64_t)ls.part * D + e] = MODE == MODE_ASSIGN_ADD ? w : acc;
       } else if (owner) {
         if (MODE == MODE_OPT_DEDUP) opt_step(kind, sg, lr, acc, w, s0, s1, ox);
+        if (MODE == MODE_SET_SUM) w = acc;
         row[e] = w;
-        if (need_state || ls.fresh) {
+        if (MODE != MODE_SET_SUM && (need_state || ls.fresh)) {
           if (opt_nstate(kind) >= 1) row[st0] = s0;
           if (opt_nstate(kind) >= 2) row[st1] = s1;
           if (OPTK == OPTK_MULTI) optx_store(sg, row, e, ox);
@@ -1420,13 +1448,15 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
         st0 = t.seg[segi].st_off + (e - t.seg[segi].w_off);
         st1 = st0 + t.seg[segi].dim;
       }
-      const bool need_state = a.mode >= MODE_OPT_SEQ;
+      const bool need_state = a.mode == MODE_OPT_SEQ || a.mode == MODE_OPT_DEDUP;
       float w, s0 = 0.f, s1 = 0.f;
       OptX ox;
       ox.gstep = a.global_step;
       if (OPTK == OPTK_MULTI && (need_state || sp.fresh))
         optx_load(t, t.seg[segi], row, e, sp.fresh != 0, sp.key, ox);
-      if (sp.fresh) {
+      if (a.mode == MODE_SET_SUM) {
+        w = 0.f;
+      } else if (sp.fresh) {
         w = row_init_value(t, sp.key, e);
         s0 = opt_nstate(kind) >= 1 ? row_init_value(t, sp.key, st0) : 0.f;
         s1 = opt_nstate(kind) >= 2 ? row_init_value(t, sp.key, st1) : 0.f;
@@ -1443,10 +1473,11 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
       } else {
         float acc = pp[0];
         for (uint32_t p = 1; p < sp.nparts; ++p) acc = acc + pp[(uint64_t)p * D];
-        opt_step(kind, t.seg[segi], a.lr[segi], acc, w, s0, s1, ox);
+        if (a.mode == MODE_SET_SUM) w = acc;
+        else opt_step(kind, t.seg[segi], a.lr[segi], acc, w, s0, s1, ox);
       }
       row[e] = w;
-      if (need_state || sp.fresh) {
+      if (a.mode != MODE_SET_SUM && (need_state || sp.fresh)) {
         if (opt_nstate(kind) >= 1) row[st0] = s0;
         if (opt_nstate(kind) >= 2) row[st1] = s1;
         if (OPTK == OPTK_MULTI) optx_store(t.seg[segi], row, e, ox);
@@ -1457,8 +1488,15 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
 }
 
 // D1: cuckoo_embedding_hash_table.cc:220-233. One thread per slot, 12 B (key + ts) per slot.
+// The two counters are bumped once per WORKGROUP (counts kept per thread over the grid-stride
+// loop, summed through LDS): an eviction that removes tens of millions of rows otherwise queues
+// millions of atomics on two words (~90 per microsecond: 100 ms for config 5's first eviction).
 __global__ void __launch_bounds__(256) k_evict(TableDev t, int64_t now) {
+  __shared__ unsigned int s_dead, s_dead_special;
+  if (threadIdx.x == 0) s_dead = s_dead_special = 0;
+  __syncthreads();
   const int64_t total = (int64_t)t.cap + 2;
+  unsigned int n_dead = 0, n_special = 0;
   for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < total;
        s += (int64_t)gridDim.x * blockDim.x) {
     const bool special = s >= (int64_t)t.cap;
@@ -1474,15 +1512,16 @@ __global__ void __launch_bounds__(256) k_evict(TableDev t, int64_t now) {
     const bool dead = live && is_expired(t, key, t.ts[s], now);
     if (dead) {
       if (!special) t.keys[s] = kTomb; else t.special[s - t.cap] = 0;
+      ++n_dead;
+      n_special += special;
     }
-    // one pair of counter updates per wave
-    const unsigned long long active = __ballot(true);
-    const unsigned long long m = __ballot(dead);
-    const unsigned long long ms = __ballot(dead && special);
-    if ((int)(threadIdx.x & 63) == __ffsll((long long)active) - 1 && m) {
-      atomicAdd(&t.counters[0], (unsigned long long)(-(long long)__popcll(m)));
-      atomicAdd(&t.counters[1], (unsigned long long)(__popcll(m) - __popcll(ms)));
-    }
+  }
+  if (n_dead) atomicAdd(&s_dead, n_dead);
+  if (n_special) atomicAdd(&s_dead_special, n_special);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_dead) {
+    atomicAdd(&t.counters[0], (unsigned long long)(-(long long)s_dead));
+    atomicAdd(&t.counters[1], (unsigned long long)(s_dead - s_dead_special));
   }
 }
 
@@ -1694,6 +1733,9 @@ static void launch_long_m(const Table* t, const ApplyArgs& a, unsigned grid, hip
     case MODE_OPT_SEQ:
       hipLaunchKernelGGL((k_apply_long<OPTK, MODE_OPT_SEQ>), dim3(grid), dim3(256), 0, st, t->d, a);
       break;
+    case MODE_SET_SUM:
+      hipLaunchKernelGGL((k_apply_long<OPTK, MODE_SET_SUM>), dim3(grid), dim3(256), 0, st, t->d, a);
+      break;
     default:
       hipLaunchKernelGGL((k_apply_long<OPTK, MODE_OPT_DEDUP>), dim3(grid), dim3(256), 0, st, t->d, a);
       break;
@@ -1731,7 +1773,8 @@ static void launch_short(const Table* t, const ApplyArgs& a, hipStream_t st) {
 // import), 1 = long segments, split into chunks (assign_add, dedup), 2 = long segments, whole
 // (per-occurrence optimizer steps).
 static int mode_class(int mode) {
-  return mode == MODE_OPT_SEQ ? 2 : (mode == MODE_ASSIGN_ADD || mode == MODE_OPT_DEDUP) ? 1 : 0;
+  return mode == MODE_OPT_SEQ ? 2
+         : (mode == MODE_ASSIGN_ADD || mode == MODE_OPT_DEDUP || mode == MODE_SET_SUM) ? 1 : 0;
 }
 static bool long_allowed(const Table* t, int mode, int64_t n) {
   // (a serving entry re-encodes after every add: its segments are walked whole, never chunked)
@@ -1951,6 +1994,7 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
   MONO_TRY(sort_pairs_u32(t->cache_slots, p.sslots, nullptr, p.sidx, (size_t)n, end_bit, tmp,
                           tmp_bytes, ss));
   ApplyArgs a{};
+  a.skip_slot = kNoSlot;
   a.n = n;
   a.skeys = p.sslots;
   a.sidx = p.sidx;
@@ -2001,6 +2045,7 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[2], st));
 
   ApplyArgs a{};
+  a.skip_slot = kNoSlot;
   a.n = n;
   a.src = src;
   a.mode = mode;
@@ -2053,6 +2098,7 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   MONO_TRY(ensure_room(t, n, st));
 
   ApplyArgs a{};
+  a.skip_slot = kNoSlot;
   a.n = n;
   a.src = src;
   a.src_ts = src_ts;
@@ -2145,11 +2191,53 @@ int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, con
   t->vec = 1;
   if (aligned4) t->vec = D % 32 == 0 ? 4 : D % 16 == 0 ? 2 : 1;
   ApplyArgs a{};
+  a.skip_slot = kNoSlot;
   a.skeys = skeys;
   a.sidx = sidx;
   a.n = n;
   a.src = src;
   a.mode = MODE_ASSIGN_ADD;
+  a.sort_err = sort_error_word();
+  MONO_TRY(t->ws.ensure(queue_bytes(n, D)));
+  uint4* heads = nullptr;
+  MONO_TRY(queue_setup(&a, (char*)t->ws.ptr, n, D, &heads, st));
+  MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st));
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+// out[key .. key + D) = src_ptrs[first occurrence] + the other occurrences in input order, for
+// every segment of the sorted keys whose class has width D (layout gradient: classes = slices).
+// Keys equal to skip_key name no destination. Same machinery as segment_add_rows.
+int segment_set_sum_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n,
+                         const float* const* src_ptrs, const uint32_t* cls, const int32_t* cls_dim,
+                         int D, bool aligned4, uint32_t skip_key, float* out, hipStream_t st) {
+  static Table ctx;
+  if (n == 0) return 0;
+  MONO_REQUIRE(D > 0 && D <= kTileFloats, "segment_set_sum_rows: dim %d exceeds %d", D, kTileFloats);
+  Table* t = &ctx;
+  t->d = TableDev{};
+  t->d.rows = out;
+  t->d.dim = D;
+  t->d.row_floats = 1;
+  t->d.n_seg = 1;
+  t->d.seg[0].dim = D;
+  t->d.seg[0].opt_kind = MONO_OPT_SGD;
+  t->d.seg[0].st_off = D;
+  t->opt_tmpl = OPTK_SGD;
+  t->vec = 1;
+  if (aligned4) t->vec = D % 32 == 0 ? 4 : D % 16 == 0 ? 2 : 1;
+  ApplyArgs a{};
+  a.skeys = skeys;
+  a.sidx = sidx;
+  a.n = n;
+  a.src_ptrs = src_ptrs;
+  a.src_aligned4 = aligned4 ? 1 : 0;
+  a.cls = cls;
+  a.cls_dim = cls_dim;
+  a.want_dim = D;
+  a.skip_slot = skip_key;
+  a.mode = MODE_SET_SUM;
   a.sort_err = sort_error_word();
   MONO_TRY(t->ws.ensure(queue_bytes(n, D)));
   uint4* heads = nullptr;

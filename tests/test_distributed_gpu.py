@@ -23,7 +23,14 @@ def _free_port():
   return p
 
 
-def _batch(rank, step):
+def _batch(rank, step, shape="small"):
+  if shape == "config4":  # BASELINE config 4's shape: one dim-64 Adagrad table, >= 1e5 ids per rank
+    rng = np.random.Generator(np.random.PCG64(77000 + 1000 * step + rank))
+    slot = rng.integers(0, 26, 120000).astype(np.int64)
+    r = (40000 * rng.random(120000) ** 3).astype(np.int64)   # bench.py's power-law skew
+    ids = {"criteo": (slot << 48) | r}
+    grads = {"criteo": rng.normal(0, 0.1, (120000, 64)).astype(np.float32)}
+    return ids, grads
   rng = np.random.Generator(np.random.PCG64(1000 * step + rank))
   ids = {"a": rng.integers(-400, 400, 3000).astype(np.int64),
          "b": (rng.integers(0, 25, 1200) * 3 + 1).astype(np.int64),
@@ -33,7 +40,7 @@ def _batch(rank, step):
   return ids, grads
 
 
-def _worker(rank, world, port, q, backend="gloo"):
+def _worker(rank, world, port, q, backend="gloo", shape="small"):
   try:
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -56,16 +63,20 @@ def _worker(rank, world, port, q, backend="gloo"):
             "b": (2, entry.SgdOptimizer(), 0.5),
             "c": (3, entry.FtrlOptimizer(initial_accumulator_value=0.1, beta=0.0,
                                          l1_regularization=0.0, l2_regularization=0.0), 0.01)}
+    if shape == "config4":
+      opts = {"criteo": (64, entry.AdagradOptimizer(initial_accumulator_value=0.1), 0.01)}
     cfgs = {k: entry.HashTableConfigInstance(cfg(d, o), [lr]) for k, (d, o, lr) in opts.items()}
     table = distributed_ps_sync.DistributedMultiTypeHashTableMpi(
         world, lambda idx: multi_type_hash_table.MultiTypeHashTable(
             cfgs, lambda slot, c: hash_table_ops.hash_table_from_config(
                 c, name_suffix="dg_%s_%d" % (slot, idx))))
     segs = {"a": cpu.seg(16, "adagrad"), "b": cpu.seg(2, "sgd"), "c": cpu.seg(3, "ftrl")}
+    if shape == "config4":
+      segs = {"criteo": cpu.seg(64, "adagrad")}
     lrs = {k: v[2] for k, v in opts.items()}
     model = [{k: cpu.OracleTable([v]) for k, v in segs.items()} for _ in range(world)]
-    for step in range(3):
-      ids, grads = _batch(rank, step)
+    for step in range(3 if shape == "small" else 2):
+      ids, grads = _batch(rank, step, shape)
       slot_to_ids = {k: torch.from_numpy(v).to(dev) for k, v in ids.items()}
       emb, bundle = table.lookup(slot_to_ids, auxiliary_bundle={})
       for k, v in ids.items():
@@ -80,19 +91,24 @@ def _worker(rank, world, port, q, backend="gloo"):
           auxiliary_bundle=bundle, global_step=step, req_time=100 + step)
       for n in range(world):
         for src in range(world):
-          s_ids, s_grads = _batch(src, step)
+          s_ids, s_grads = _batch(src, step, shape)
           for k in sorted(s_ids):
             v, g = s_ids[k], s_grads[k]
             sel = np.mod(v, world) == n
             v, g = v[sel], g[sel]
-            uniq, first = np.unique(v, return_index=True)
-            order = uniq[np.argsort(first)]
+            uniq, first, inv = np.unique(v, return_index=True, return_inverse=True)
+            by_first = np.argsort(first)
+            order = uniq[by_first]
+            rank_of = np.empty(len(uniq), np.int64)
+            rank_of[by_first] = np.arange(len(uniq))
+            # the requesting rank sums duplicates in input order, first term copied (F2 gradient):
+            # ufunc.at is unbuffered and walks its operands in order
             summed = np.zeros((len(order), g.shape[1]), np.float32)
-            for i, u in enumerate(order):
-              acc = np.zeros(g.shape[1], np.float32)
-              for row in g[v == u]:
-                acc = acc + row
-              summed[i] = acc
+            if len(v):
+              summed[rank_of[inv[first]]] = g[first]
+              rest = np.ones(len(v), bool)
+              rest[first] = False
+              np.add.at(summed, rank_of[inv[rest]], g[rest])
             model[n][k].apply_gradients(order, summed, [lrs[k]], req_time=100 + step,
                                         global_step=step)
     for k, ht in table._table._hash_tables.items():
@@ -119,6 +135,25 @@ def test_world2_exchange_on_hip_ops():
   for p in ps:
     p.start()
   res = [q.get(timeout=150) for _ in ps]
+  for p in ps:
+    p.join(timeout=30)
+  for rank, err in res:
+    assert err is None, "rank %d failed:\n%s" % (rank, err)
+
+
+def test_world2_exchange_config4_shape():
+  """BASELINE config 4's table (dim 64, Adagrad, bench.py's skewed FIDs, 1.2e5 ids per rank and
+  step) through the world-2 exchange: embeddings and the owner shards' final state against the
+  serial oracle model, bit for bit. (The N = 8 routing of the same ids, both shard rules, is
+  checked against the oracle in tests/test_ops_gpu.py::test_reorder_config4_routing.)"""
+  world = 2
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  ps = [ctx.Process(target=_worker, args=(r, world, port, q, "gloo", "config4")) for r in range(world)]
+  for p in ps:
+    p.start()
+  res = [q.get(timeout=280) for _ in ps]
   for p in ps:
     p.join(timeout=30)
   for rank, err in res:

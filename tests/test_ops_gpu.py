@@ -62,6 +62,26 @@ def test_fused_reorder_random_vs_oracle(ops, monkeypatch, n_shards, rank0):
       assert np.array_equal(a.cpu().numpy().reshape(-1), b)
 
 
+@pytest.mark.parametrize("rank0", ["0", "1"])
+def test_reorder_config4_routing(ops, monkeypatch, rank0):
+  """BASELINE config 4's routing: one merged dim-64 slot, 1.2e5 skewed FIDs (bench.py's stream),
+  8 shards, plain floormod(fid, 8) and the reference-default rank-0-empty rule
+  1 + floormod(fid, 7) (distribution_ops.py:255-272): ids, shard sizes and offsets against the
+  oracle, bit for bit."""
+  d_ops = ops[0]
+  monkeypatch.setenv("MONOLITH_SYNC_EMPTY_RANK0_PS_SHARD", rank0)
+  rng = np.random.Generator(np.random.PCG64(4400 + int(rank0)))
+  slot = rng.integers(0, 26, 120000).astype(np.int64)
+  ids = (slot << 48) | (40000 * rng.random(120000) ** 3).astype(np.int64)
+  o, s, ss, of = d_ops.fused_reorder_by_indices([T(ids, torch.int64)], 8, [64])
+  eo, es, ess, eof = cpu.fused_reorder_by_indices([ids], 8, [64], shard_rule=int(rank0))
+  assert np.array_equal(o.cpu().numpy(), eo)
+  assert np.array_equal(s.numpy(), es) and np.array_equal(ss.numpy(), ess)
+  assert np.array_equal(of[0].cpu().numpy().reshape(-1), eof[0])
+  if rank0 == "1":
+    assert s.numpy()[0] == 0  # rank 0 holds no rows under the reference-default rule
+
+
 def test_fused_gather_and_gradient(ops):
   """distribution_ops_fused_test.py:113-119 layout + random case; the gradient accumulates
   duplicates in input order (ops/map_id_to_embedding_op.cc:294-343) -> bit-exact."""
