@@ -30,7 +30,8 @@ int filter_dev_view(void* filter, FilterDev* out, hipStream_t) {
 __global__ void k_filter_rotate_decide(FilterDev f) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   uint32_t head = f.state[0];
-  uint64_t ne = f.num_elements[head];
+  uint64_t ne = 0;
+  for (int sh = 0; sh < kFilterShards; ++sh) ne += *filter_counter(f, head, (uint32_t)sh);
   if (ne > f.capacity) ne = f.capacity;
   if (ne + 1 >= f.capacity) {  // HashFilter::full(): num_elements >= capacity - 1
     head = head + 1 == f.n_blocks ? 0 : head + 1;
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(256) k_filter_rotate_clear(FilterDev f) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < f.stride;
        i += (uint64_t)gridDim.x * blockDim.x)
     base[i] = 0;
-  if (blockIdx.x == 0 && threadIdx.x == 0) f.num_elements[blk] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < kFilterShards) *filter_counter(f, blk, threadIdx.x) = 0;
 }
 
 int filter_after_batch(void* filter, hipStream_t st) {
@@ -183,10 +184,10 @@ int mono_filter_create(int kind, int64_t capacity, int split_num, int default_th
     size_t cells = (size_t)d.n_blocks * d.stride;
     cells = (cells + 1) & ~(size_t)1;
     if (hipMalloc((void**)&d.cells, cells * 2) != hipSuccess ||
-        hipMalloc((void**)&d.num_elements, d.n_blocks * 4) != hipSuccess ||
+        hipMalloc((void**)&d.num_elements, filter_counter_words(d.n_blocks) * 4) != hipSuccess ||
         hipMalloc((void**)&d.state, 4 * 4) != hipSuccess ||
         hipMemset(d.cells, 0, cells * 2) != hipSuccess ||
-        hipMemset(d.num_elements, 0, d.n_blocks * 4) != hipSuccess ||
+        hipMemset(d.num_elements, 0, filter_counter_words(d.n_blocks) * 4) != hipSuccess ||
         hipMemset(d.state, 0, 16) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
       mono_filter_destroy(f);
       return fail("mono_filter_create: cannot allocate %zu filter cells", cells);
@@ -264,10 +265,14 @@ int mono_filter_state(void* filter, int64_t* h_out, int64_t h_out_len, void* str
   if (f->kind != 1) return 0;
   hipStream_t st = (hipStream_t)stream;
   uint32_t state[4];
-  std::vector<uint32_t> ne(f->d.n_blocks);
+  std::vector<uint32_t> raw(filter_counter_words(f->d.n_blocks));
   MONO_HIP(hipMemcpyAsync(state, f->d.state, 16, hipMemcpyDeviceToHost, st));
-  MONO_HIP(hipMemcpyAsync(ne.data(), f->d.num_elements, ne.size() * 4, hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipMemcpyAsync(raw.data(), f->d.num_elements, raw.size() * 4, hipMemcpyDeviceToHost, st));
   MONO_HIP(hipStreamSynchronize(st));
+  std::vector<uint64_t> ne(f->d.n_blocks, 0);
+  for (uint32_t b = 0; b < f->d.n_blocks; ++b)
+    for (int sh = 0; sh < kFilterShards; ++sh)
+      ne[b] += raw[((size_t)b * kFilterShards + sh) * kFilterShardStride];
   int64_t vals[5] = {state[0], state[1], state[2], f->d.n_blocks, (int64_t)f->d.total_size};
   for (int i = 0; i < 5 && i < h_out_len; ++i) h_out[i] = vals[i];
   for (uint32_t b = 0; b < f->d.n_blocks && 5 + b < h_out_len; ++b)
@@ -287,11 +292,14 @@ int mono_filter_export_split(void* filter, int split, uint16_t* h_cells, int64_t
   MONO_REQUIRE((uint64_t)n_cells == f->d.stride, "mono_filter_export_split: %lld cells, block has %llu",
                (long long)n_cells, (unsigned long long)f->d.stride);
   hipStream_t st = (hipStream_t)stream;
-  uint32_t ne = 0;
+  uint64_t ne = 0;
+  std::vector<uint32_t> raw((size_t)kFilterShards * kFilterShardStride);
   MONO_HIP(hipMemcpyAsync(h_cells, f->d.cells + (size_t)split * f->d.stride, (size_t)n_cells * 2,
                           hipMemcpyDeviceToHost, st));
-  MONO_HIP(hipMemcpyAsync(&ne, f->d.num_elements + split, 4, hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipMemcpyAsync(raw.data(), f->d.num_elements + (size_t)split * raw.size(), raw.size() * 4,
+                          hipMemcpyDeviceToHost, st));
   MONO_HIP(hipStreamSynchronize(st));
+  for (int sh = 0; sh < kFilterShards; ++sh) ne += raw[(size_t)sh * kFilterShardStride];
   if (h_num_elements) *h_num_elements = (int64_t)std::min<uint64_t>(ne, f->d.capacity);
   return 0;
 }
@@ -311,7 +319,11 @@ int mono_filter_import_split(void* filter, int split, const uint16_t* h_cells, i
   const uint32_t ne = (uint32_t)std::min<uint64_t>((uint64_t)num_elements, f->d.capacity);
   MONO_HIP(hipMemcpyAsync(f->d.cells + (size_t)split * f->d.stride, h_cells, (size_t)n_cells * 2,
                           hipMemcpyHostToDevice, st));
-  MONO_HIP(hipMemcpyAsync(f->d.num_elements + split, &ne, 4, hipMemcpyHostToDevice, st));
+  // (the restored count goes to shard 0, the other shards of the block restart at zero)
+  std::vector<uint32_t> raw((size_t)kFilterShards * kFilterShardStride, 0u);
+  raw[0] = ne;
+  MONO_HIP(hipMemcpyAsync(f->d.num_elements + (size_t)split * raw.size(), raw.data(), raw.size() * 4,
+                          hipMemcpyHostToDevice, st));
   MONO_HIP(hipStreamSynchronize(st));
   return 0;
 }

@@ -5,7 +5,7 @@
 // 1..29 key bits. At that size a general-purpose library sort is launch-bound (buffer fills and
 // look-back state between passes). Two paths, both 8-bit digits over 8192-element tiles:
 //
-// up to 512 tiles (4.19 M pairs: every sort of the headline workload) — pass 0 as below (its
+// up to 1024 tiles (8.39 M pairs: every sort of the benchmarked workloads) — pass 0 as below (its
 // hist kernel also zeroes the scratch of the later passes, its scatter kernel accumulates pass
 // 1's digit totals), then ONE kernel per pass:
 //   k_sort_fused    ranks its tile, publishes the tile's digit counts as self-validating words
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
 // Tile numbers are handed out by an atomic ticket, so every tile a workgroup waits for has
 // already started and publishes before it waits on anything: the wait always ends. The spin is
 // bounded all the same; a time-out raises err[0] (mono_sort_error) instead of hanging the GPU.
-constexpr int kFusedMaxTiles = 512;
+constexpr int kFusedMaxTiles = 1024;  // 8.4 M pairs (config 3's layout gradient sorts 6.5 M)
 constexpr int kFusedMaxPasses = 4;
 constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr uint32_t kRowReady = 0x80000000u;  // a tile holds at most 8192 elements

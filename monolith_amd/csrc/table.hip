@@ -137,6 +137,7 @@ struct Table {
   int64_t max_update_ts = 0;
   int32_t* slot_expire_dev = nullptr;
   Workspace ws;
+  Workspace ws_gated;  // the gated remainder of a write call with a hash filter
   // optional per-phase timing of the write path (mono_table_profile)
   bool profile = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -581,6 +582,70 @@ __global__ void __launch_bounds__(256) k_claim_pending(TableDev t, const int64_t
         }
         if (sub == 0) slot_out[i] = slot;
       }
+    }
+  }
+}
+
+// Write path with a hash filter, step 1: which positions name ids the table already holds? Those
+// never touch the filter (bridge :274-275, :288-289) and take the plain path by slot; the others
+// are marked (slot = `skip`, unknown = 1) for the gated path. Nothing is claimed here. Uses the
+// lookup's slot record like k_claim_pending.
+__global__ void __launch_bounds__(256) k_resolve_known(TableDev t, const int64_t* __restrict__ ids,
+                                                       int64_t n, uint32_t* slot_out,
+                                                       int32_t* unknown, uint32_t skip,
+                                                       const int64_t* __restrict__ cache_ids,
+                                                       const uint32_t* __restrict__ cache_slots,
+                                                       int64_t cache_n) {
+  const int lane = threadIdx.x & 63, sub = lane_sub(), gshift = lane_gshift(), grp = lane >> 3;
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / 64);
+  for (int64_t base = ((int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 64; base < n;
+       base += nwaves * 64) {
+    bool pend = false;
+    if (base + lane < n) {
+      const int64_t i = base + lane;
+      uint32_t sv = kNoSlot;
+      if (i < cache_n && cache_ids[i] == ids[i]) sv = cache_slots[i];
+      if (sv != kNoSlot) {
+        slot_out[i] = sv;
+        unknown[i] = 0;
+      } else {
+        pend = true;
+      }
+    }
+    unsigned long long m = __ballot(pend);
+    while (m) {  // wave-uniform: up to eight pending positions per round
+      unsigned long long rest = m;
+      int mine = -1;
+      for (int g = 0; g < 8; ++g) {
+        if (!rest) break;
+        const int b = __ffsll((long long)rest) - 1;
+        if (g == grp) mine = b;
+        rest &= rest - 1;
+      }
+      m = rest;
+      if (mine >= 0) {
+        const int64_t i = base + mine;
+        const uint32_t slot = group_find(t, ids[i], sub, gshift);
+        if (sub == 0) {
+          slot_out[i] = slot == kNoSlot ? skip : slot;
+          unknown[i] = slot == kNoSlot;
+        }
+      }
+    }
+  }
+}
+
+// ... step 2: the unknown positions, in input order (pos = exclusive scan of `unknown`)
+__global__ void __launch_bounds__(256) k_compact_unknown(const int64_t* __restrict__ ids,
+                                                         const int32_t* __restrict__ unknown,
+                                                         const int32_t* __restrict__ pos, int64_t n,
+                                                         int64_t* __restrict__ unk_ids,
+                                                         uint32_t* __restrict__ unk_idx) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    if (unknown[i]) {
+      unk_ids[pos[i]] = ids[i];
+      unk_idx[pos[i]] = (uint32_t)i;
     }
   }
 }
@@ -2068,6 +2133,97 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   return 0;
 }
 
+// Write path with a hash filter. Ids the table already holds never touch the filter, and in a
+// trained table that is nearly all of them: they are resolved to slots and take the plain path
+// (32-bit slot sort, k_classify, the apply kernels). Only the unknown remainder — compacted in
+// input order — is grouped by its 64-bit key and walked by the gated head kernel (filter counts,
+// admission, slot claims: the closed forms of SURVEY 8a). The two parts touch disjoint rows.
+static int write_path_gated(Table* t, void* filter, ApplyArgs a, const int64_t* ids, int64_t n,
+                            hipStream_t st) {
+  const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
+  const uint32_t skip = (uint32_t)(t->d.cap + 2);
+  const int end_bit = bits_for(t->d.cap + 2);
+  const size_t tmp32 = (sort_pairs_tmp_bytes((size_t)n, end_bit) + 255) & ~(size_t)255;
+  size_t scan_tmp = 0;
+  MONO_HIP(rocprim::exclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int32_t*)nullptr, 0,
+                                   (size_t)n, rocprim::plus<int32_t>(), st));
+  scan_tmp = (scan_tmp + 255) & ~(size_t)255;
+  const size_t q_bytes = (queue_bytes(n, t->d.dim) + 255) & ~(size_t)255;
+  // [slot_in | unknown | pos | slot_out | idx_out | sort scratch | scan scratch | queues]
+  const size_t part1 = 5 * n_al * sizeof(uint32_t) + tmp32 + scan_tmp + q_bytes;
+  MONO_TRY(t->ws.ensure(part1));
+  uint32_t* slot_in = (uint32_t*)t->ws.ptr;
+  int32_t* unknown = (int32_t*)(slot_in + n_al);
+  int32_t* pos = unknown + n_al;
+  uint32_t* slot_out = (uint32_t*)(pos + n_al);
+  uint32_t* idx_out = slot_out + n_al;
+  char* tmp = (char*)(idx_out + n_al);
+  char* scan_buf = tmp + tmp32;
+  char* q_base = scan_buf + scan_tmp;
+  hipLaunchKernelGGL(k_resolve_known, dim3(grid_for(n, 1024)), dim3(256), 0, st, t->d, ids, n, slot_in,
+                     unknown, skip, t->cache_ids, t->cache_slots, t->cache_n);
+  MONO_HIP(hipGetLastError());
+  MONO_HIP(rocprim::exclusive_scan(scan_buf, scan_tmp, unknown, pos, 0, (size_t)n,
+                                   rocprim::plus<int32_t>(), st));
+  int32_t h_last[2] = {0, 0};
+  MONO_HIP(hipMemcpyAsync(&h_last[0], pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipMemcpyAsync(&h_last[1], unknown + (n - 1), 4, hipMemcpyDeviceToHost, st));
+  MONO_TRY(prep_setup(t));  // (its event marks the read-back below)
+  MONO_HIP(hipEventRecord(t->prep.ev_verify, st));
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
+  // known ids: the plain path; it runs while the host waits for the count of unknown ones
+  {
+    ApplyArgs k = a;
+    k.from_keys = 0;
+    k.filt = FilterDev{};
+    k.skip_slot = skip;
+    k.sort_err = sort_error_word();
+    MONO_TRY(sort_pairs_u32(slot_in, slot_out, nullptr, idx_out, (size_t)n, end_bit, tmp, tmp32, st));
+    k.skeys = slot_out;
+    k.sidx = idx_out;
+    uint4* heads = nullptr;
+    MONO_TRY(queue_setup(&k, q_base, n, t->d.dim, &heads, st));
+    if (t->profile) MONO_HIP(hipEventRecord(t->ev[2], st));
+    MONO_TRY(launch_apply(t, k, heads, k.qcount + 1, st));
+    MONO_HIP(hipGetLastError());
+  }
+  MONO_HIP(hipEventSynchronize(t->prep.ev_verify));
+  const int64_t U = (int64_t)h_last[0] + h_last[1];
+  if (U > 0) {
+    const size_t u_al = ((size_t)U + 63) & ~(size_t)63;
+    size_t tmp64 = 0;
+    MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp64, (int64_t*)nullptr, (int64_t*)nullptr,
+                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)U, 0, 64, st));
+    tmp64 = (tmp64 + 255) & ~(size_t)255;
+    const size_t q2 = (queue_bytes(U, t->d.dim) + 255) & ~(size_t)255;
+    // a workspace of its own: the first part's arrays are still being read on the device
+    MONO_TRY(t->ws_gated.ensure(2 * u_al * sizeof(int64_t) + 2 * u_al * sizeof(uint32_t) + tmp64 + q2));
+    int64_t* unk_ids = (int64_t*)t->ws_gated.ptr;
+    int64_t* key_out = unk_ids + u_al;
+    uint32_t* unk_idx = (uint32_t*)(key_out + u_al);
+    uint32_t* idx_out2 = unk_idx + u_al;
+    char* tmp2 = (char*)(idx_out2 + u_al);
+    char* q_base2 = tmp2 + tmp64;
+    hipLaunchKernelGGL(k_compact_unknown, dim3(grid_for(n, 256)), dim3(256), 0, st, ids, unknown, pos, n,
+                       unk_ids, unk_idx);
+    MONO_HIP(hipGetLastError());
+    MONO_HIP(rocprim::radix_sort_pairs(tmp2, tmp64, unk_ids, key_out, unk_idx, idx_out2, (size_t)U, 0,
+                                       64, st));
+    ApplyArgs g = a;
+    g.n = U;
+    g.from_keys = 1;
+    g.skeys = key_out;
+    g.sidx = idx_out2;
+    g.sort_err = nullptr;
+    uint4* heads = nullptr;
+    MONO_TRY(queue_setup(&g, q_base2, U, t->d.dim, &heads, st));
+    MONO_TRY(launch_apply(t, g, heads, g.qcount + 1, st));
+    MONO_HIP(hipGetLastError());
+  }
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
+  return filter_after_batch(filter, st);
+}
+
 // The whole write path. `filter` gates inserts of unknown ids (nullptr / dummy = no gate).
 static int write_path(Table* t, void* filter, const int64_t* ids, const float* src,
                       const uint32_t* src_ts, int64_t n, int mode, const float* lrs, int n_lrs,
@@ -2142,22 +2298,7 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
     a.skeys = slot_out;
     a.sidx = idx_out;
   } else {
-    size_t tmp_bytes = 0;
-    MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (int64_t*)nullptr, (int64_t*)nullptr,
-                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 64, st));
-    tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
-    MONO_TRY(t->ws.ensure(n_al * sizeof(int64_t) + 2 * n_al * sizeof(uint32_t) + tmp_bytes + q_bytes));
-    int64_t* key_out = (int64_t*)t->ws.ptr;
-    q_base = (char*)t->ws.ptr + n_al * sizeof(int64_t) + 2 * n_al * sizeof(uint32_t) + tmp_bytes;
-    uint32_t* idx_in = (uint32_t*)(key_out + n_al);
-    uint32_t* idx_out = idx_in + n_al;
-    void* tmp = idx_out + n_al;
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(n, 256)), dim3(256), 0, st, idx_in, n);
-    if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
-    MONO_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, ids, key_out, idx_in, idx_out, (size_t)n, 0,
-                                       64, st));
-    a.skeys = key_out;
-    a.sidx = idx_out;
+    return write_path_gated(t, filter, a, ids, n, st);
   }
   uint4* heads = nullptr;
   MONO_TRY(queue_setup(&a, q_base, n, t->d.dim, &heads, st, !from_keys));
@@ -2418,6 +2559,7 @@ int mono_table_destroy(void* table) {
   if (t->cache_slots) (void)hipFree(t->cache_slots);
   prep_destroy(t);
   t->ws.release();
+  t->ws_gated.release();
   for (int i = 0; i < 4; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
   for (int i = 0; i < 2; ++i)

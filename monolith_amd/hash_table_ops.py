@@ -20,6 +20,9 @@ from monolith_amd import hash_filter_ops
 _DEVICE = "cuda"
 
 
+_WARNED_MULTI_THREAD_DEDUP = False
+
+
 def _dev():
   return torch.device(_DEVICE, torch.cuda.current_device())
 
@@ -253,6 +256,19 @@ class HashTable(BaseHashTable):
 
   def apply_gradients(self, ids, grads, global_step, use_multi_threads=False, enable_dedup=False,
                       req_time=None) -> "HashTable":
+    if use_multi_threads and enable_dedup:
+      # ops/hash_table_update_op.cc:114-131 cuts the batch into as many ranges as TensorFlow's
+      # Shard() finds worker threads for and dedups inside each range: which duplicates meet
+      # depends on the host's thread pool. Here the batch is ONE range (the reference's own result
+      # whenever Shard() decides on a single shard); said once, loudly, because a stateful
+      # optimizer gives a different row when a key's duplicates straddle two of those ranges.
+      global _WARNED_MULTI_THREAD_DEDUP
+      if not _WARNED_MULTI_THREAD_DEDUP:
+        import warnings
+        warnings.warn("apply_gradients(use_multi_threads=True, enable_dedup=True): the reference "
+                      "dedups per thread range (machine dependent); monolith_amd dedups over the "
+                      "whole batch, i.e. the single-range result", RuntimeWarning, stacklevel=2)
+        _WARNED_MULTI_THREAD_DEDUP = True
     ids, grads = _ids(ids), _f32(grads)
     self._check_values(ids, grads)
     lrs = self.learning_rate_tensor
