@@ -24,6 +24,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import re
 import sys
 import time
 
@@ -692,24 +693,27 @@ def main():
     kern["k_apply"] = (kapply_ms, (n - n_long) * 4 * D + (uniq * n - u_long) * (2 * (4 * D + 4 * D) + 4))
   else:
     kern["k_apply"] = kern["apply phase"]
-  dom = max(("k_lookup", "k_apply"), key=lambda k: kern[k][0])
+  # the dominant single kernel: k_apply (mono_table_lookup is two kernels, k_probe + a row gather
+  # throttled on purpose so that the sort of the update order overlaps it: kernel_ms carries it)
+  dom = "k_apply"
   achieved = kern[dom][1] / (kern[dom][0] * 1e-3) / 1e9
   step_gbs = (lookup_bytes + update_bytes) / (ms_per_step * 1e-3) / 1e9
   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE + WRITE_SIZE,
   # separate rocprofv3 --pmc runs of this same command; calibration note in the summary file)
   traffic, traffic_src = None, None
   try:
-    with open(os.path.join(ROOT, "profiles", "r01_i_pmc_summary.json")) as f:
+    import glob
+    pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*_pmc_summary.json")))[-1]
+    with open(pmc_file) as f:
       pmc = json.load(f)["kernels"]
-    members = {"k_lookup": ["mono::k_lookup<4>"],
-               "k_apply": ["mono::k_apply<2, 1, 3>"] if kapply_ms == kapply_ms else
-                          ["mono::k_classify", "mono::k_apply<2, 1, 3>", "mono::k_apply_long<1, 3>",
-                           "mono::k_combine<1>"]}[dom]
+    members = (["mono::k_apply<2, 1, 3>"] if kapply_ms == kapply_ms else
+               ["mono::k_classify", "mono::k_apply<2, 1, 3>", "mono::k_apply_long<1, 3>",
+                "mono::k_combine<1>"])
     if args.batch == 65536 and args.rows == 1e8 and args.skew == 3.0:
       traffic = sum((pmc[m]["FETCH_SIZE_KB_last_launch"] + pmc[m]["WRITE_SIZE_KB_last_launch"]) *
                     1024.0 for m in members)
-      traffic_src = "profiles/r01_i_pmc_summary.json (" + " + ".join(members) + ")"
-  except (OSError, KeyError, ValueError):
+      traffic_src = "profiles/%s (%s)" % (os.path.basename(pmc_file), " + ".join(members))
+  except (OSError, KeyError, ValueError, IndexError):
     pass
 
   res = {
@@ -731,7 +735,7 @@ def main():
                                   "'apply phase' = k_classify, then k_apply beside k_apply_long "
                                   "(hot keys) + k_combine, on the caller's stream",
                    "long_segment_occurrences": n_long, "long_segment_keys": u_long,
-                   "random_64B_line_ceiling_GBps": 3000.0,
+                   "measured_random_access_ceiling": measured_ceiling(),
                    "kernel_ms": {k: v[0] for k, v in kern.items()},
                    "step_algorithmic_GBps": step_gbs, "step_frac": step_gbs / HBM_PEAK_GBS},
   }
@@ -743,6 +747,23 @@ def main():
     emit(res)
   if world > 1:
     torch.distributed.destroy_process_group()
+
+
+def measured_ceiling():
+  """The random-access ceiling of this GPU as scripts/exp_ceiling.hip measured it (committed output:
+  profiles/r02_ceiling.txt): independent random reads over a 32 GiB footprint, by access width."""
+  path = os.path.join(ROOT, "profiles", "r02_ceiling.txt")
+  res = {"source": "profiles/r02_ceiling.txt (scripts/exp_ceiling.hip)"}
+  try:
+    with open(path) as f:
+      for line in f:
+        m = re.match(r"read (64|128) B over +32\.00 GiB .* ([0-9.]+) G acc/s +([0-9.]+) GB/s", line)
+        if m:
+          res["random_%sB_Greq_per_s" % m.group(1)] = float(m.group(2))
+          res["random_%sB_GBps" % m.group(1)] = float(m.group(3))
+  except OSError:
+    return None
+  return res
 
 
 if __name__ == "__main__":

@@ -1,11 +1,12 @@
 #!/bin/bash
 # One round's measurement set on the GPU box (run through gpurun from the repo root):
-#   scripts/profile_round.sh r01_f
+#   scripts/profile_round.sh r02_e [anchor kernel of a step, default k_probe]
 # bench line, rocprofv3 --kernel-trace --stats of the same command, FETCH_SIZE / WRITE_SIZE passes
 # (each its own run), the sharded pipeline at N=1. Summaries land in gpurun_out/<tag>_*; the
 # rocprof databases are deleted on the box (gpurun_out is capped at 64 MiB).
 set -e -o pipefail
 T=$1
+A=${2:-k_probe}
 R=$(pwd)
 O=$R/gpurun_out
 mkdir -p $O
@@ -14,9 +15,9 @@ timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $O/prof_$T -o p -- python3
   > $O/${T}_bench.json 2> $O/${T}_bench.err
 cd $R
 DB=$(find $O/prof_$T -name '*.db' | head -1)
-python3 scripts/db_to_stats.py $DB $O/${T}_kernel_stats_steps.csv k_lookup
+python3 scripts/db_to_stats.py $DB $O/${T}_kernel_stats_steps.csv $A
 python3 scripts/db_to_stats.py $DB $O/${T}_kernel_stats_all.csv
-python3 scripts/timeline.py $DB k_lookup > $O/${T}_step_timeline.txt
+python3 scripts/timeline.py $DB $A > $O/${T}_step_timeline.txt
 rm -rf $O/prof_$T
 cd /tmp
 timeout -s KILL 150 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_f -o f -- python3 $R/bench.py \
