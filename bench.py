@@ -162,10 +162,18 @@ def main_sharded(args, rank, world, device):
   uniq = float(np.mean([torch.unique(b).numel() / n for b in pool]))
 
   state = {"t": table}
+  # The reorder of batch i + 1 is issued on a side stream while step i runs, as the reference's
+  # input pipeline does (distributed_ps_sync.py:313-331, early_reorder_indicies_res_pack): every
+  # step still does one reorder, one lookup and one update; --no-prefetch keeps them in line.
+  side = torch.cuda.Stream(device) if not args.no_prefetch else None
 
   def step(i):
     ids = {"criteo": pool[i % n_pool]}
-    emb, bundle = state["t"].lookup(ids, auxiliary_bundle={})
+    pack = state.pop("pack", None)
+    emb, bundle = state["t"].lookup(ids, auxiliary_bundle={}, early_reorder_indicies_res_pack=pack)
+    if side is not None:
+      with torch.cuda.stream(side):
+        state["pack"] = state["t"].reorder_begin({"criteo": pool[(i + 1) % n_pool]})
     state["t"] = state["t"].apply_gradients({"criteo": (ids["criteo"], grad)}, bundle,
                                             global_step=i, req_time=10 + i)
     return emb
@@ -210,6 +218,7 @@ def main_sharded(args, rank, world, device):
                                                           world, D, args.batch, args.backend),
                  "fids_per_step_per_gpu": n, "unique_ratio_per_rank": uniq, "skew": args.skew,
                  "parallelism": "table sharded over %d GPUs, all-to-all exchange" % world,
+                 "reorder": "one batch ahead on a side stream" if side is not None else "in line",
                  "populate_s": t_pop, "table_rows": total_rows},
       "roofline": {"bound": "hbm", "kernel": "whole step (per GPU)", "achieved": step_gbs,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
@@ -550,6 +559,8 @@ def main():
   ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) | gloo (single-GPU rehearsal)")
   ap.add_argument("--sharded", action="store_true",
                   help="run the N > 1 exchange pipeline even at N = 1 (profiling aid)")
+  ap.add_argument("--no-prefetch", action="store_true",
+                  help="sharded pipeline: reorder each batch in line instead of one batch ahead")
   ap.add_argument("--config", type=int, default=0, help="2 | 3 | 4 | 5 (default: 2, or 4 when N > 1)")
   ap.add_argument("--dim", type=int, default=0, help="config 4 / --sharded: row width (default 64 / 16)")
   args = ap.parse_args()

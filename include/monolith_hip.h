@@ -231,12 +231,25 @@ int mono_tables_fused_apply_gradient(void* const* tables, void* const* filters, 
 /* ops/fused_reorder_by_indices.cc:36-112 + distribution_ops.py:255-272. inputs: M device id
  * arrays (host array of device pointers); shard_rule 0 = floormod(id, N), 1 = 1 + floormod(id, N-1).
  * out_ids has room for sum(lens) ids; *h_n_unique = ids written; out_offsets: M device int32
- * arrays shaped like the inputs; h_shard_sizes[N], h_sharded_slot_sizes[N*M] host; synchronises. */
+ * arrays shaped like the inputs; h_shard_sizes[N], h_sharded_slot_sizes[N*M] host. Returns as soon
+ * as the sizes have reached the host: out_ids / out_offsets are complete in STREAM order (work
+ * queued on `stream` afterwards sees them), not necessarily when the call returns. */
 int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h_lens, int M, int N,
                                   const int32_t* h_dims, int shard_rule, int64_t* out_ids,
                                   int64_t* h_n_unique, int32_t* h_shard_sizes,
                                   int32_t* h_sharded_slot_sizes, int32_t* const* out_offsets,
                                   void* stream);
+/* The same in two halves, for callers that compute the reorder ahead of the step that consumes it
+ * (the reference does so in its input pipeline: distributed_ps_sync.py:313-331,
+ * early_reorder_indicies_res_pack). begin launches on `stream` and returns; finish blocks until the
+ * sizes are on the host and reports them. One reorder may be pending at a time; the gradient plan
+ * token (below) is valid after finish. begin may be given a side stream: out_ids / out_offsets are
+ * complete in THAT stream's order (make the consumer's stream wait for an event recorded on it). */
+int mono_fused_reorder_begin(const int64_t* const* inputs, const int64_t* h_lens, int M, int N,
+                             const int32_t* h_dims, int shard_rule, int64_t* out_ids,
+                             int32_t* const* out_offsets, void* stream);
+int mono_fused_reorder_finish(int64_t* h_n_unique, int32_t* h_shard_sizes,
+                              int32_t* h_sharded_slot_sizes);
 /* ShardingSparseFidsV2 on device-resident ragged FIDs: data/kernels/parse_sparse_feature.cc:173-211
  * (FillFidList: shard = uint64(fid) % ps_num), :213-288 (CreateOffsetTensor),
  * parse_sparse_feature.h:1472-1680 (FeatureParallelUniqueParse), data/parsers.py:402-456.
@@ -263,6 +276,22 @@ int mono_fused_gather_embeddings_by_input_gradient(int64_t fused_len, const floa
                                                    const int32_t* const* offsets,
                                                    const int64_t* h_lens, const int32_t* h_dims,
                                                    int M, float* out, void* stream);
+/* The same gradient with the order of summation prepared ahead of time. mono_fused_reorder_by_indices
+ * sorts and classifies the offsets it has just written on a stream of its own, while the host
+ * waits for its sizes; mono_fused_reorder_last_plan() returns the token of that plan (0 = none).
+ * The call below uses the plan when `plan` names one of the two most recent plans AND offsets /
+ * h_lens / h_dims are the very arrays that reorder wrote (same device pointers, unmodified since);
+ * otherwise it does what the unplanned call does. Same result either way (same input order).
+ * No counterpart in the reference: its gradient op recomputes nothing because it scatters with
+ * atomics (map_id_to_embedding.cu.cc:76-119); here the sum is ordered, and the plan takes the
+ * ordering off the backward pass. */
+int64_t mono_fused_reorder_last_plan(void);
+int mono_fused_gather_embeddings_by_input_gradient_planned(int64_t plan, int64_t fused_len,
+                                                           const float* const* grads,
+                                                           const int32_t* const* offsets,
+                                                           const int64_t* h_lens,
+                                                           const int32_t* h_dims, int M, float* out,
+                                                           void* stream);
 
 /* ---- pooling ---- */
 /* ops/reduce_op.cc:29-51 / :55-87: out[batch, dim] zero-filled then summed in input order. */

@@ -42,6 +42,7 @@ def _load():
         "g.build()'` or `make -C monolith_amd/csrc`; there is no CPU fallback." % LIB_PATH)
   lib = C.CDLL(LIB_PATH)
   lib.mono_last_error.restype = C.c_char_p
+  lib.mono_fused_reorder_last_plan.restype = C.c_int64
   return lib
 
 

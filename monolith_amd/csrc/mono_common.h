@@ -100,6 +100,16 @@ int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, con
 int segment_set_sum_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n,
                          const float* const* src_ptrs, const uint32_t* cls, const int32_t* cls_dim,
                          int D, bool aligned4, uint32_t skip_key, float* out, hipStream_t st);
+// host-side call timing, printed at exit when MONO_HOST_PROF is set (table.hip)
+bool host_prof_on();
+double host_now();
+void host_tick(const char* name, double* t0);  // adds (now - *t0) to `name`, restarts *t0
+size_t segment_plan_bytes(int64_t n, int D);
+int segment_plan_classify(const uint32_t* skeys, const uint32_t* sidx, int64_t n, int D, char* q_base,
+                          hipStream_t st);
+int segment_set_sum_planned(const uint32_t* skeys, const uint32_t* sidx, int64_t n, const float* src,
+                            int D, bool aligned4, float* out, char* q_base, hipEvent_t ready,
+                            hipStream_t st);
 
 // table.hip, for the fused lookup + pool of layout.hip: the slot of every id (0xFFFFFFFF = not in
 // the table), and where the rows of a table live (weights first: columns [0, dim) of a row of

@@ -30,18 +30,123 @@ static int bits_for_u(uint64_t max_value) {
   return b;
 }
 
-static int sort_pairs(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
-                      size_t n, int end_bit, hipStream_t st) {
-  const size_t tmp = sort_pairs_tmp_bytes(n, end_bit);
-  MONO_TRY(g_ws_sort.ensure(tmp));
-  return sort_pairs_u32(kin, kout, vin, vout, n, end_bit, g_ws_sort.ptr, tmp, st);
+// F2-gradient plan. The gradient of fused_gather_embeddings_by_input sums the gradient rows of
+// every occurrence into the row of its unique id, in input order: a stable sort of (offset,
+// occurrence) plus the segment classification, ~120 us of latency-bound work that depends on
+// nothing but the offsets F1 has just produced. F1 therefore runs it on a stream of its own
+// while the host waits for F1's sizes (the GPU would otherwise idle there), and hands out a token;
+// the gradient call that presents the token and the very same offset arrays only launches the
+// sum kernels. Two plans are kept, so an F1 issued one step ahead does not displace the plan of
+// the step still to be differentiated. MONO_GRAD_PLAN=0 switches it off.
+struct GradPlan {
+  uint64_t token = 0;
+  int M = 0;
+  std::vector<const int32_t*> offs;
+  std::vector<int64_t> lens;
+  std::vector<int32_t> dims;
+  std::vector<size_t> o_skey, o_sidx, o_q;  // byte offsets into ws, per slot
+  int64_t covered = 0;  // floats [0, covered) each belong to the row of some occurrence
+  Workspace ws;
+  hipEvent_t ready = nullptr;
+};
+static GradPlan g_plans[2];
+static uint64_t g_plan_seq = 0;
+static hipStream_t g_plan_stream = nullptr;
+static hipEvent_t g_plan_src = nullptr, g_ev_sizes = nullptr;
+static int32_t* g_pinned = nullptr;
+static size_t g_pinned_words = 0;
+
+static bool grad_plan_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("MONO_GRAD_PLAN");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
 }
 
-static int exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n, hipStream_t st) {
+static int pinned_words(size_t words, int32_t** out) {
+  if (words > g_pinned_words) {
+    if (g_pinned) MONO_HIP(hipHostFree(g_pinned));
+    g_pinned = nullptr;
+    g_pinned_words = 0;
+    const size_t want = std::max<size_t>(words, 1024);
+    MONO_HIP(hipHostMalloc((void**)&g_pinned, want * sizeof(int32_t), hipHostMallocDefault));
+    g_pinned_words = want;
+  }
+  *out = g_pinned;
+  return 0;
+}
+
+// Sort + classify every slot's offsets on the plan stream, behind `st`'s work so far.
+static int grad_plan_build(const std::vector<int32_t*>& offs, const int64_t* h_lens,
+                           const int32_t* h_dims, int M, int64_t total, hipStream_t st,
+                           GradPlan** out) {
+  *out = nullptr;
+  if (!grad_plan_enabled()) return 0;
+  int32_t max_dim = 1;
+  for (int m = 0; m < M; ++m) max_dim = std::max(max_dim, h_dims[m]);
+  if ((uint64_t)total * (uint64_t)max_dim >= 0x7FFFFFF0ull) return 0;
+  if (!g_plan_stream) {
+    MONO_HIP(hipStreamCreateWithFlags(&g_plan_stream, hipStreamNonBlocking));
+    MONO_HIP(hipEventCreateWithFlags(&g_plan_src, hipEventDisableTiming));
+  }
+  GradPlan& p = g_plans[(g_plan_seq + 1) & 1];
+  p.token = 0;
+  if (!p.ready) MONO_HIP(hipEventCreateWithFlags(&p.ready, hipEventDisableTiming));
+  const int end_bit = bits_for_u((uint64_t)total * (uint64_t)max_dim);
+  p.M = M;
+  p.offs.assign(offs.begin(), offs.end());
+  p.lens.assign(h_lens, h_lens + M);
+  p.dims.assign(h_dims, h_dims + M);
+  p.o_skey.assign(M, 0);
+  p.o_sidx.assign(M, 0);
+  p.o_q.assign(M, 0);
+  size_t bytes = 0, tmp_max = 0;
+  for (int m = 0; m < M; ++m) {
+    const size_t n_al = ((size_t)h_lens[m] + 63) & ~(size_t)63;
+    p.o_skey[m] = bytes;
+    bytes += n_al * sizeof(uint32_t);
+    p.o_sidx[m] = bytes;
+    bytes += n_al * sizeof(uint32_t);
+    bytes = (bytes + 255) & ~(size_t)255;
+    p.o_q[m] = bytes;
+    bytes += h_lens[m] ? segment_plan_bytes(h_lens[m], h_dims[m]) : 0;
+    if (h_lens[m]) tmp_max = std::max(tmp_max, sort_pairs_tmp_bytes((size_t)h_lens[m], end_bit));
+  }
+  tmp_max = (tmp_max + 255) & ~(size_t)255;
+  MONO_TRY(p.ws.ensure(bytes + tmp_max + 256));
+  char* base = (char*)p.ws.ptr;
+  void* tmp = base + bytes;
+  MONO_HIP(hipEventRecord(g_plan_src, st));
+  MONO_HIP(hipStreamWaitEvent(g_plan_stream, g_plan_src, 0));
+  for (int m = 0; m < M; ++m) {
+    if (h_lens[m] == 0) continue;
+    uint32_t* skey = (uint32_t*)(base + p.o_skey[m]);
+    uint32_t* sidx = (uint32_t*)(base + p.o_sidx[m]);
+    // keys = the float offsets themselves, values = occurrence positions (the sort's default)
+    MONO_TRY(sort_pairs_u32((const uint32_t*)offs[m], skey, nullptr, sidx, (size_t)h_lens[m], end_bit,
+                            tmp, tmp_max, g_plan_stream));
+    MONO_TRY(segment_plan_classify(skey, sidx, h_lens[m], h_dims[m], base + p.o_q[m], g_plan_stream));
+  }
+  MONO_HIP(hipEventRecord(p.ready, g_plan_stream));
+  *out = &p;
+  return 0;
+}
+static int64_t g_last_plan_token = 0;
+
+static int sort_pairs(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
+                      size_t n, int end_bit, hipStream_t st, Workspace* ws = &g_ws_sort) {
+  const size_t tmp = sort_pairs_tmp_bytes(n, end_bit);
+  MONO_TRY(ws->ensure(tmp));
+  return sort_pairs_u32(kin, kout, vin, vout, n, end_bit, ws->ptr, tmp, st);
+}
+
+static int exclusive_scan_i32(const int32_t* in, int32_t* out, size_t n, hipStream_t st,
+                              Workspace* ws = &g_ws_sort) {
   size_t tmp = 0;
   MONO_HIP(rocprim::exclusive_scan(nullptr, tmp, in, out, 0, n, rocprim::plus<int32_t>(), st));
-  MONO_TRY(g_ws_sort.ensure(tmp + 256));
-  MONO_HIP(rocprim::exclusive_scan(g_ws_sort.ptr, tmp, in, out, 0, n, rocprim::plus<int32_t>(), st));
+  MONO_TRY(ws->ensure(tmp + 256));
+  MONO_HIP(rocprim::exclusive_scan(ws->ptr, tmp, in, out, 0, n, rocprim::plus<int32_t>(), st));
   return 0;
 }
 
@@ -719,14 +824,40 @@ int mono_fused_gather_embeddings_by_input(const float* fused, int64_t fused_len,
   return 0;
 }
 
-int mono_fused_gather_embeddings_by_input_gradient(int64_t fused_len, const float* const* grads,
-                                                   const int32_t* const* offsets,
-                                                   const int64_t* h_lens, const int32_t* h_dims,
-                                                   int M, float* out, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
-  MONO_HIP(hipMemsetAsync(out, 0, (size_t)fused_len * sizeof(float), st));
+static int gather_gradient(int64_t plan_token, int64_t fused_len, const float* const* grads,
+                           const int32_t* const* offsets, const int64_t* h_lens,
+                           const int32_t* h_dims, int M, float* out, hipStream_t st) {
+  double hp = host_prof_on() ? host_now() : 0.0;
   bool aligned4 = ((uintptr_t)out & 15) == 0;
-  for (int m = 0; m < M; ++m) aligned4 = aligned4 && (h_dims[m] % 4 == 0);
+  for (int m = 0; m < M; ++m)
+    aligned4 = aligned4 && (h_dims[m] % 4 == 0) && ((uintptr_t)grads[m] & 15) == 0;
+  // the plan F1 prepared for exactly these offset arrays, if the caller names it
+  GradPlan* plan = nullptr;
+  if (plan_token != 0)
+    for (GradPlan& p : g_plans)
+      if (p.token == (uint64_t)plan_token && p.M == M && fused_len >= p.covered) {
+        bool same = true;
+        for (int m = 0; m < M; ++m)
+          same = same && p.offs[m] == offsets[m] && p.lens[m] == h_lens[m] && p.dims[m] == h_dims[m];
+        if (same) plan = &p;
+      }
+  if (plan) {
+    // every float below `covered` is written by the sum itself (each unique id has an occurrence)
+    if (fused_len > plan->covered)
+      MONO_HIP(hipMemsetAsync(out + plan->covered, 0, (size_t)(fused_len - plan->covered) * sizeof(float),
+                              st));
+    char* base = (char*)plan->ws.ptr;
+    host_tick("grad: find plan + tail fill", &hp);
+    for (int m = 0; m < M; ++m) {
+      if (h_lens[m] == 0) continue;
+      MONO_TRY(segment_set_sum_planned((const uint32_t*)(base + plan->o_skey[m]),
+                                       (const uint32_t*)(base + plan->o_sidx[m]), h_lens[m], grads[m],
+                                       h_dims[m], aligned4, out, base + plan->o_q[m], plan->ready, st));
+    }
+    host_tick("grad: planned sums (all slots)", &hp);
+    return 0;
+  }
+  MONO_HIP(hipMemsetAsync(out, 0, (size_t)fused_len * sizeof(float), st));
   for (int m = 0; m < M; ++m) {
     const int64_t n = h_lens[m];
     if (n == 0) continue;
@@ -746,18 +877,54 @@ int mono_fused_gather_embeddings_by_input_gradient(int64_t fused_len, const floa
   return 0;
 }
 
-int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h_lens, int M, int N,
-                                  const int32_t* h_dims, int shard_rule, int64_t* out_ids,
-                                  int64_t* h_n_unique, int32_t* h_shard_sizes,
-                                  int32_t* h_sharded_slot_sizes, int32_t* const* out_offsets,
-                                  void* stream) {
+int mono_fused_gather_embeddings_by_input_gradient(int64_t fused_len, const float* const* grads,
+                                                   const int32_t* const* offsets,
+                                                   const int64_t* h_lens, const int32_t* h_dims,
+                                                   int M, float* out, void* stream) {
+  return gather_gradient(0, fused_len, grads, offsets, h_lens, h_dims, M, out, (hipStream_t)stream);
+}
+
+int mono_fused_gather_embeddings_by_input_gradient_planned(int64_t plan, int64_t fused_len,
+                                                           const float* const* grads,
+                                                           const int32_t* const* offsets,
+                                                           const int64_t* h_lens,
+                                                           const int32_t* h_dims, int M, float* out,
+                                                           void* stream) {
+  return gather_gradient(plan, fused_len, grads, offsets, h_lens, h_dims, M, out,
+                         (hipStream_t)stream);
+}
+
+int64_t mono_fused_reorder_last_plan(void) { return g_last_plan_token; }
+
+// F1 in two halves. begin launches everything on `stream` and returns; finish waits for the
+// sizes (an event right behind the histogram, ahead of the offsets and the gradient plan) and
+// reports them. One reorder may be pending at a time. The reorder has workspaces of its own, so a
+// caller may issue begin on a side stream one step ahead (the reference computes the reorder in
+// its input pipeline, distributed_ps_sync.py early_reorder_indicies_res_pack) while other ops of
+// this library run on the main stream.
+struct ReorderPending {
+  bool active = false;
+  int N = 0, M = 0;
+  std::vector<int32_t> dims;
+  GradPlan* plan = nullptr;
+  int32_t* pin = nullptr;
+};
+static ReorderPending g_reorder;
+static Workspace g_ws_reorder, g_ws_reorder_sort;
+
+static int reorder_begin(const int64_t* const* inputs, const int64_t* h_lens, int M, int N,
+                         const int32_t* h_dims, int shard_rule, int64_t* out_ids,
+                         int32_t* const* out_offsets, hipStream_t st) {
   MONO_REQUIRE(M >= 1 && N >= 1, "mono_fused_reorder_by_indices: M %d N %d", M, N);
   MONO_REQUIRE(shard_rule == 0 || (shard_rule == 1 && N >= 2),
                "mono_fused_reorder_by_indices: shard_rule %d with N %d", shard_rule, N);
-  hipStream_t st = (hipStream_t)stream;
-  for (int i = 0; i < N; ++i) h_shard_sizes[i] = 0;
-  for (int i = 0; i < N * M; ++i) h_sharded_slot_sizes[i] = 0;
-  *h_n_unique = 0;
+  MONO_REQUIRE(!g_reorder.active, "mono_fused_reorder_begin: the previous reorder was never finished");
+  g_reorder.N = N;
+  g_reorder.M = M;
+  g_reorder.dims.assign(h_dims, h_dims + M);
+  g_reorder.plan = nullptr;
+  g_reorder.pin = nullptr;
+  g_last_plan_token = 0;
   std::vector<SlotMeta> sm(M);
   int64_t total = 0, cells = 0;
   for (int m = 0; m < M; ++m) {
@@ -773,7 +940,9 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
     total += h_lens[m];
     cells += (int64_t)sz + 1;
   }
-  if (total == 0) return 0;
+  g_reorder.active = true;
+  if (total == 0) return 0;  // (finish reports zeros)
+  g_reorder.active = false;
   MONO_REQUIRE(total < (int64_t)0xFFFFFFF0ll && cells < (int64_t)0xFFFFFFF0ll,
                "mono_fused_reorder_by_indices: too many ids");
   const size_t t_al = ((size_t)total + 63) & ~(size_t)63;
@@ -792,8 +961,8 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   const size_t off_scan = off_dims + t_al * 4;
   const size_t off_hist = off_scan + t_al * 4;
   bytes = off_hist + hist_al * 4;
-  MONO_TRY(g_ws.ensure(bytes));
-  char* base = (char*)g_ws.ptr;
+  MONO_TRY(g_ws_reorder.ensure(bytes));
+  char* base = (char*)g_ws_reorder.ptr;
   SlotMeta* d_sm = (SlotMeta*)(base + off_meta);
   uint32_t* hfirst = (uint32_t*)(base + off_hfirst);
   uint32_t* hcell = (uint32_t*)(base + off_hcell);
@@ -809,40 +978,102 @@ int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h
   MONO_HIP(hipMemsetAsync(hist, 0, hist_al * 4, st));
   ReorderArgs a{M, N, shard_rule, total};
   const dim3 grid(grid_for(total, 256)), blk(256);
+  double hp = host_prof_on() ? host_now() : 0.0;
   hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hfirst, hcell, 0);
   hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hfirst, hcell, 1);
   hipLaunchKernelGGL(k_reorder_keys, grid, blk, 0, st, a, d_sm, hfirst, hcell, skey, sidx);
   MONO_HIP(hipGetLastError());
-  MONO_TRY(sort_pairs(skey, skey2, sidx, sidx2, (size_t)total,
-                                    bits_for_u((uint64_t)N * M), st));
+  MONO_TRY(sort_pairs(skey, skey2, sidx, sidx2, (size_t)total, bits_for_u((uint64_t)N * M), st,
+                      &g_ws_reorder_sort));
   bool uniform = true;  // one dim for every slot: offsets need no scan
   for (int m = 1; m < M; ++m) uniform = uniform && h_dims[m] == h_dims[0];
   uniform = uniform && total * (int64_t)h_dims[0] < (int64_t)0x7FFFFFF0;
   hipLaunchKernelGGL(k_reorder_hist, dim3(grid_for((int64_t)N * M, 256)), blk, 0, st, a, skey2, hist);
+  MONO_HIP(hipGetLastError());
+  // The sizes are final here: they go to the host now (pinned staging, an event of their own), and
+  // everything below — the embedding offsets and the plan of the gradient — runs on the device
+  // while the host wakes up and prepares the exchange.
+  int32_t* pin = nullptr;
+  MONO_TRY(pinned_words((size_t)N * M + 1, &pin));
+  if (!g_ev_sizes) MONO_HIP(hipEventCreateWithFlags(&g_ev_sizes, hipEventDisableTiming));
+  MONO_HIP(hipMemcpyAsync(pin, hist, (size_t)N * M * 4, hipMemcpyDeviceToHost, st));
+  pin[(size_t)N * M] = 0;
+  if (uint32_t* w = sort_error_word())
+    MONO_HIP(hipMemcpyAsync(pin + (size_t)N * M, w, 4, hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipEventRecord(g_ev_sizes, st));
+  host_tick("reorder: launches up to the sizes", &hp);
   if (!uniform) {
     hipLaunchKernelGGL(k_reorder_dims, grid, blk, 0, st, a, d_sm, skey2, dims);
     MONO_HIP(hipGetLastError());
-    MONO_TRY(exclusive_scan_i32(dims, scan, (size_t)total, st));
+    MONO_TRY(exclusive_scan_i32(dims, scan, (size_t)total, st, &g_ws_reorder_sort));
   }
   hipLaunchKernelGGL(k_reorder_emit, grid, blk, 0, st, a, d_sm, skey2, sidx2,
                      uniform ? (const int32_t*)nullptr : scan, uniform ? h_dims[0] : 0, hcell,
                      hfirst, out_ids);
   hipLaunchKernelGGL(k_reorder_offsets, grid, blk, 0, st, a, d_sm, hfirst, hcell);
   MONO_HIP(hipGetLastError());
-  MONO_HIP(hipMemcpyAsync(h_sharded_slot_sizes, hist, (size_t)N * M * 4, hipMemcpyDeviceToHost, st));
-  uint32_t h_sort_err = 0;
-  if (uint32_t* w = sort_error_word())
-    MONO_HIP(hipMemcpyAsync(&h_sort_err, w, sizeof(h_sort_err), hipMemcpyDeviceToHost, st));
-  MONO_HIP(hipStreamSynchronize(st));
-  MONO_TRY(sort_error_report(h_sort_err));  // the sizes come out of a sort: never hand out stale ones
-  int64_t uniq = 0;
+  host_tick("reorder: emit + offsets launches", &hp);
+  {
+    std::vector<int32_t*> offs(out_offsets, out_offsets + M);
+    MONO_TRY(grad_plan_build(offs, h_lens, h_dims, M, total, st, &g_reorder.plan));
+  }
+  host_tick("reorder: plan build launches", &hp);
+  g_reorder.pin = pin;
+  g_reorder.active = true;
+  return 0;
+}
+
+static int reorder_finish(int64_t* h_n_unique, int32_t* h_shard_sizes, int32_t* h_sharded_slot_sizes) {
+  MONO_REQUIRE(g_reorder.active, "mono_fused_reorder_finish: no reorder is pending");
+  g_reorder.active = false;
+  const int N = g_reorder.N, M = g_reorder.M;
+  for (int i = 0; i < N; ++i) h_shard_sizes[i] = 0;
+  for (int i = 0; i < N * M; ++i) h_sharded_slot_sizes[i] = 0;
+  *h_n_unique = 0;
+  const int32_t* pin = g_reorder.pin;
+  if (!pin) return 0;  // no ids at all
+  double hp = host_prof_on() ? host_now() : 0.0;
+  MONO_HIP(hipEventSynchronize(g_ev_sizes));
+  host_tick("reorder: sync sizes (incl. GPU wait)", &hp);
+  MONO_TRY(sort_error_report((uint32_t)pin[(size_t)N * M]));  // the sizes come out of a sort: never hand out stale ones
+  int64_t uniq = 0, covered = 0;
   for (int n = 0; n < N; ++n)
     for (int m = 0; m < M; ++m) {
-      h_shard_sizes[n] += h_sharded_slot_sizes[n * M + m];
-      uniq += h_sharded_slot_sizes[n * M + m];
+      const int32_t c = pin[n * M + m];
+      h_sharded_slot_sizes[n * M + m] = c;
+      h_shard_sizes[n] += c;
+      uniq += c;
+      covered += (int64_t)c * g_reorder.dims[m];
     }
   *h_n_unique = uniq;
+  if (GradPlan* plan = g_reorder.plan) {
+    plan->covered = covered;
+    plan->token = ++g_plan_seq;
+    g_last_plan_token = (int64_t)plan->token;
+  }
   return 0;
+}
+
+int mono_fused_reorder_begin(const int64_t* const* inputs, const int64_t* h_lens, int M, int N,
+                             const int32_t* h_dims, int shard_rule, int64_t* out_ids,
+                             int32_t* const* out_offsets, void* stream) {
+  return reorder_begin(inputs, h_lens, M, N, h_dims, shard_rule, out_ids, out_offsets,
+                       (hipStream_t)stream);
+}
+
+int mono_fused_reorder_finish(int64_t* h_n_unique, int32_t* h_shard_sizes,
+                              int32_t* h_sharded_slot_sizes) {
+  return reorder_finish(h_n_unique, h_shard_sizes, h_sharded_slot_sizes);
+}
+
+int mono_fused_reorder_by_indices(const int64_t* const* inputs, const int64_t* h_lens, int M, int N,
+                                  const int32_t* h_dims, int shard_rule, int64_t* out_ids,
+                                  int64_t* h_n_unique, int32_t* h_shard_sizes,
+                                  int32_t* h_sharded_slot_sizes, int32_t* const* out_offsets,
+                                  void* stream) {
+  MONO_TRY(reorder_begin(inputs, h_lens, M, N, h_dims, shard_rule, out_ids, out_offsets,
+                         (hipStream_t)stream));
+  return reorder_finish(h_n_unique, h_shard_sizes, h_sharded_slot_sizes);
 }
 
 int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* row_splits,

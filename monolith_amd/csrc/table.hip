@@ -20,6 +20,7 @@
 // sub-group walks a key's occurrences in input order — which is also what makes duplicate
 // handling bit-exact with the reference's sequential loops (SURVEY.md §8a closed forms).
 #include <algorithm>
+#include <ctime>
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -123,6 +124,10 @@ struct Table {
     int mode_class = -1;          // what k_classify was run for (-1: not run)
     hipStream_t stream = nullptr;
     hipEvent_t ev_probe = nullptr, ev_ready = nullptr, ev_verify = nullptr;
+    // row gather of the prepared lookup: throttled (the update follows at once and waits for the
+    // order) or at full depth (the order is ready long before the update asks for it)
+    bool gather_full = false;
+    int slack_run = 0, full_backoff = 0, full_backoff_len = 64;
     uint32_t* d_flags = nullptr;  // [0] ids the lookup did not find  [1] positions k_verify found changed
     uint32_t* h_flags = nullptr;  // pinned host copy
     uint32_t seen_changed = 0;    // d_flags[1] as of the last read-back (it only grows)
@@ -691,8 +696,13 @@ struct ApplyArgs {
   int want_dim;      // 0 = every segment
   uint32_t skip_slot;  // sorted key that marks "no destination" (besides kNoSlot)
 };
+// PTRS: can this instantiation be given per-occurrence source pointers at all? (Only the set-sum
+// mode is; a run-time test in every other kernel's gradient loads cost the headline k_apply a
+// quarter of its speed.)
+template <bool PTRS>
 __device__ __forceinline__ const float* src_row(const ApplyArgs& a, uint32_t idx, int D) {
-  return a.src_ptrs ? a.src_ptrs[idx] : a.src + (uint64_t)idx * D;
+  if (PTRS && a.src_ptrs) return a.src_ptrs[idx];
+  return a.src + (uint64_t)idx * D;
 }
 
 // A key with many occurrences in one batch (a Zipf head): handed to a whole workgroup.
@@ -932,6 +942,7 @@ __device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t e
 template <int V, int OPTK, int MODE_T = -1>
 __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
   const int mode = MODE_T >= 0 ? MODE_T : a.mode;
+  constexpr bool kPtrs = MODE_T < 0 || MODE_T == MODE_SET_SUM;
   // the fixed-mode instantiation is launched on the no-filter path only: slots are resolved and
   // k_classify has compacted the segment heads
   const bool from_keys = MODE_T >= 0 ? false : (a.from_keys != 0);
@@ -1105,7 +1116,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
     }
     // --- walk the occurrences in input order
     if (mode == MODE_ASSIGN) {
-      vload<V>(w, src_row(a, a.sidx[end - 1], D) + e0);
+      vload<V>(w, src_row<kPtrs>(a, a.sidx[end - 1], D) + e0);
       if (OPTK == OPTK_MULTI && t.serving) {
 #pragma unroll
         for (int q = 0; q < V; ++q) w[q] = comp_q(t.seg[segi[q]], w[q]);
@@ -1117,17 +1128,17 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
         // time makes a 96-occurrence segment a ~150 us chain of memory round trips)
         for (; p + 4 <= end; p += 4) {
           float g0[V], g1[V], g2[V], g3[V];
-          vload<V>(g0, src_row(a, a.sidx[p], D) + e0);
-          vload<V>(g1, src_row(a, a.sidx[p + 1], D) + e0);
-          vload<V>(g2, src_row(a, a.sidx[p + 2], D) + e0);
-          vload<V>(g3, src_row(a, a.sidx[p + 3], D) + e0);
+          vload<V>(g0, src_row<kPtrs>(a, a.sidx[p], D) + e0);
+          vload<V>(g1, src_row<kPtrs>(a, a.sidx[p + 1], D) + e0);
+          vload<V>(g2, src_row<kPtrs>(a, a.sidx[p + 2], D) + e0);
+          vload<V>(g3, src_row<kPtrs>(a, a.sidx[p + 3], D) + e0);
 #pragma unroll
           for (int q = 0; q < V; ++q) w[q] = (((w[q] + g0[q]) + g1[q]) + g2[q]) + g3[q];
         }
       }
       for (; p < end; ++p) {
         float g[V];
-        vload<V>(g, src_row(a, a.sidx[p], D) + e0);
+        vload<V>(g, src_row<kPtrs>(a, a.sidx[p], D) + e0);
 #pragma unroll
         for (int q = 0; q < V; ++q) w[q] += g[q];
         if (OPTK == OPTK_MULTI && t.serving) {  // every AssignAdd re-encodes (entry_accessor.cc:70-77)
@@ -1151,10 +1162,10 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       for (; p + 4 <= end; p += 4) {  // the steps depend on each other, the row loads do not
         const uint32_t i0 = a.sidx[p], i1 = a.sidx[p + 1], i2 = a.sidx[p + 2], i3 = a.sidx[p + 3];
         float g0[V], g1[V], g2[V], g3[V];
-        vload<V>(g0, src_row(a, i0, D) + e0);
-        vload<V>(g1, src_row(a, i1, D) + e0);
-        vload<V>(g2, src_row(a, i2, D) + e0);
-        vload<V>(g3, src_row(a, i3, D) + e0);
+        vload<V>(g0, src_row<kPtrs>(a, i0, D) + e0);
+        vload<V>(g1, src_row<kPtrs>(a, i1, D) + e0);
+        vload<V>(g2, src_row<kPtrs>(a, i2, D) + e0);
+        vload<V>(g3, src_row<kPtrs>(a, i3, D) + e0);
         step_one(g0, i0);
         step_one(g1, i1);
         step_one(g2, i2);
@@ -1163,25 +1174,25 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       for (; p < end; ++p) {
         float g[V];
         const uint32_t i0 = a.sidx[p];
-        vload<V>(g, src_row(a, i0, D) + e0);
+        vload<V>(g, src_row<kPtrs>(a, i0, D) + e0);
         step_one(g, i0);
       }
     } else {  // MODE_OPT_DEDUP: in-order sum (bridge :251-266), then one step
       float acc[V];
-      vload<V>(acc, src_row(a, first == j ? idx0 : a.sidx[first], D) + e0);
+      vload<V>(acc, src_row<kPtrs>(a, first == j ? idx0 : a.sidx[first], D) + e0);
       int64_t p = first + 1;
       for (; p + 4 <= end; p += 4) {  // 4 independent loads in flight, adds stay in order
         float g0[V], g1[V], g2[V], g3[V];
-        vload<V>(g0, src_row(a, a.sidx[p], D) + e0);
-        vload<V>(g1, src_row(a, a.sidx[p + 1], D) + e0);
-        vload<V>(g2, src_row(a, a.sidx[p + 2], D) + e0);
-        vload<V>(g3, src_row(a, a.sidx[p + 3], D) + e0);
+        vload<V>(g0, src_row<kPtrs>(a, a.sidx[p], D) + e0);
+        vload<V>(g1, src_row<kPtrs>(a, a.sidx[p + 1], D) + e0);
+        vload<V>(g2, src_row<kPtrs>(a, a.sidx[p + 2], D) + e0);
+        vload<V>(g3, src_row<kPtrs>(a, a.sidx[p + 3], D) + e0);
 #pragma unroll
         for (int q = 0; q < V; ++q) acc[q] = (((acc[q] + g0[q]) + g1[q]) + g2[q]) + g3[q];
       }
       for (; p < end; ++p) {
         float g[V];
-        vload<V>(g, src_row(a, a.sidx[p], D) + e0);
+        vload<V>(g, src_row<kPtrs>(a, a.sidx[p], D) + e0);
 #pragma unroll
         for (int q = 0; q < V; ++q) acc[q] = acc[q] + g[q];
       }
@@ -1378,7 +1389,7 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
         if (vec4) {
 #pragma unroll
           for (int k = 0; k < kLStage4; ++k) {
-            S[k] = (r < rows) ? *reinterpret_cast<const float4*>(src_row(a, ix[r], D) + eb + 4 * c)
+            S[k] = (r < rows) ? *reinterpret_cast<const float4*>(src_row<MODE == MODE_SET_SUM>(a, ix[r], D) + eb + 4 * c)
                               : make_float4(0.f, 0.f, 0.f, 0.f);
             r += dr;
             c += dc;
@@ -1388,7 +1399,7 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
           float* Sf = reinterpret_cast<float*>(&S[0]);
 #pragma unroll
           for (int k = 0; k < 4 * kLStage4; ++k) {
-            Sf[k] = (r < rows) ? src_row(a, ix[r], D)[eb + c] : 0.f;
+            Sf[k] = (r < rows) ? src_row<MODE == MODE_SET_SUM>(a, ix[r], D)[eb + c] : 0.f;
             r += dr;
             c += dc;
             if (c >= cpr) { c -= cpr; ++r; }
@@ -1777,6 +1788,10 @@ static void launch_apply_vo(const Table* t, const ApplyArgs& a, hipStream_t st) 
     hipLaunchKernelGGL((k_apply<V, OPTK, MODE_OPT_SEQ>), grid, dim3(256), 0, st, t->d, a);
   else if (!a.from_keys && a.heads && a.mode == MODE_ASSIGN_ADD)
     hipLaunchKernelGGL((k_apply<V, OPTK, MODE_ASSIGN_ADD>), grid, dim3(256), 0, st, t->d, a);
+  else if (OPTK == OPTK_SGD && !a.from_keys && a.heads && a.mode == MODE_SET_SUM)
+    // (the segment sums of the stateless ops: F2 gradient, layout gradient)
+    hipLaunchKernelGGL((k_apply<V, OPTK == OPTK_SGD ? OPTK : OPTK_SGD, MODE_SET_SUM>), grid, dim3(256), 0, st,
+                       t->d, a);
   else
     hipLaunchKernelGGL((k_apply<V, OPTK>), grid, dim3(256), 0, st, t->d, a);
 }
@@ -1852,13 +1867,59 @@ static void launch_classify(const ApplyArgs& a, bool allow_long, uint4* heads, h
                      dim3(kClsThreads), 0, st, a, allow_long ? 1 : 0, heads);
 }
 
+// ---- host-side call timing (MONO_HOST_PROF=1): where the launch path spends its microseconds ----
+bool host_prof_on() {
+  static const bool v = getenv("MONO_HOST_PROF") != nullptr;
+  return v;
+}
+struct HostProfRow { const char* name; double us; long calls; double min_us; };
+static HostProfRow g_host_prof[64];
+static int g_host_prof_n = 0;
+double host_now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+static void host_prof_dump() {
+  for (int i = 0; i < g_host_prof_n; ++i)
+    fprintf(stderr, "hostprof %-40s calls %8ld  avg %8.2f us  min %8.2f us\n", g_host_prof[i].name,
+            g_host_prof[i].calls, g_host_prof[i].us / std::max(1l, g_host_prof[i].calls),
+            g_host_prof[i].min_us);
+}
+// adds (now - *t0) to `name` and restarts *t0
+void host_tick(const char* name, double* t0) {
+  if (!host_prof_on()) return;
+  const double now = host_now();
+  int i = 0;
+  for (; i < g_host_prof_n; ++i)
+    if (g_host_prof[i].name == name) break;
+  if (i == g_host_prof_n) {
+    if (g_host_prof_n == 64) return;
+    if (g_host_prof_n == 0) atexit(host_prof_dump);
+    g_host_prof[g_host_prof_n++] = HostProfRow{name, 0.0, 0, 1e30};
+  }
+  g_host_prof[i].us += now - *t0;
+  g_host_prof[i].min_us = std::min(g_host_prof[i].min_us, now - *t0);
+  g_host_prof[i].calls += 1;
+  *t0 = host_now();
+}
+
 // classified: k_classify has already run on these sorted arrays (for this mode's class)
 // `ready`: an event of another stream the (already classified) input still waits for; both apply
 // streams wait on it directly, so neither start pays a fork behind the other.
+// `ready_old`: the event is most likely over already (a plan made long ago): one wait on the
+// caller's stream ahead of the fork instead of one per apply stream (a cross-stream wait costs
+// 5-17 us of host time each, MONO_HOST_PROF).
 static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, hipStream_t st,
-                        bool classified = false, hipEvent_t ready = nullptr) {
+                        bool classified = false, hipEvent_t ready = nullptr, bool ready_old = false) {
   const bool allow_long = long_allowed(t, a.mode, a.n);
   const unsigned lgrid = (unsigned)std::min<int64_t>(a.n / kLongSeg + 1, 1024);
+  double hp = host_prof_on() ? host_now() : 0.0;
+  if (ready && ready_old) {
+    MONO_HIP(hipStreamWaitEvent(st, ready, 0));
+    ready = nullptr;
+    host_tick("apply: wait old ready (st)", &hp);
+  }
   if (a.from_keys) {
     // filter path: the sub-group kernel resolves / gates / claims and feeds the long queue
     launch_short(t, a, st);
@@ -1890,19 +1951,27 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
   // long-lived) are resident before the sub-group kernel's ~27k short workgroups flood the
   // dispatcher from the auxiliary stream; the other order leaves the long kernel to run
   // mostly after the short one has drained.
+  hp = host_prof_on() ? host_now() : 0.0;
   MONO_HIP(hipEventRecord(t->ev_fork, st));
+  host_tick(a.mode == MODE_SET_SUM ? "gradsum: record fork" : "apply: record fork", &hp);
   if (ready) MONO_HIP(hipStreamWaitEvent(st, ready, 0));
+  host_tick(a.mode == MODE_SET_SUM ? "gradsum: wait ready (st)" : "apply: wait ready (st)", &hp);
   launch_long_o(t, a, lgrid, st);
+  host_tick(a.mode == MODE_SET_SUM ? "gradsum: launch long+combine" : "apply: launch long+combine", &hp);
   MONO_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
   if (ready) MONO_HIP(hipStreamWaitEvent(t->aux, ready, 0));
+  host_tick(a.mode == MODE_SET_SUM ? "gradsum: aux waits" : "apply: aux waits", &hp);
   if (t->profile) MONO_HIP(hipEventRecord(t->ev_k[0], t->aux));
   launch_short(t, a, t->aux);
+  host_tick(a.mode == MODE_SET_SUM ? "gradsum: launch short" : "apply: launch short", &hp);
   if (t->profile) {
     MONO_HIP(hipEventRecord(t->ev_k[1], t->aux));
     t->ev_k_valid = true;
   }
   MONO_HIP(hipEventRecord(t->ev_join, t->aux));
+  host_tick(a.mode == MODE_SET_SUM ? "gradsum: record join" : "apply: record join", &hp);
   MONO_HIP(hipStreamWaitEvent(st, t->ev_join, 0));
+  host_tick(a.mode == MODE_SET_SUM ? "gradsum: wait join" : "apply: wait join", &hp);
   return 0;
 }
 
@@ -2014,25 +2083,36 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
   p.sidx = p.sslots + n_al;
   void* tmp = p.sidx + n_al;
   p.q_base = (char*)tmp + tmp_bytes;
+  double hp = host_prof_on() ? host_now() : 0.0;
   hipLaunchKernelGGL(k_probe, dim3(grid_for(n, 32 * kIlpP)), dim3(256), 0, st, t->d, ids, n,
                      t->cache_ids, t->cache_slots, p.d_flags, (uint32_t*)p.q_base);
   MONO_HIP(hipGetLastError());
+  host_tick("lookup: launch probe", &hp);
   MONO_HIP(hipEventRecord(p.ev_probe, st));
+  host_tick("lookup: record probe", &hp);
   // Row gather on the caller's stream, deliberately throttled: one workgroup per CU, two rows in
   // flight per lane group. At full depth (4096 workgroups x 8 rows) the gather keeps hundreds of
   // thousands of requests queued in the memory pipeline, every load of the latency-bound sort
   // beside it waits behind them (its first kernel took 52 us instead of 7, stream priority or
   // not: profiles/r02_a, r02_b), and nothing overlaps. Throttled, the gather takes ~2x longer but
   // the sort runs inside it: 388 -> 365 us per step (profiles/r02_sweep_gather.txt).
+  // Whether the throttle pays depends on what the caller does between this lookup and the update:
+  // back to back (the plain training step) the update waits for the order, and the throttle wins;
+  // with other work in between (the sharded pipeline: row exchange, F2 gather, gradient sum) the
+  // order is ready long before, and the throttle only slows the gather down. try_prepared sees
+  // which case it is (was the order complete when the update asked?) and flips gather_full.
   const int D = t->d.dim;
-  static const int gather_blocks = [] {
+  static const int env_blocks = [] {
     const char* e = getenv("MONO_GATHER_BLOCKS");
-    return e ? atoi(e) : 256;
+    return e ? atoi(e) : 0;
   }();
-  static const int gather_ilp = [] {
+  static const int env_ilp = [] {
     const char* e = getenv("MONO_GATHER_ILP");
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : 0;
   }();
+  const bool full = p.gather_full && env_blocks == 0 && env_ilp == 0;
+  const int gather_blocks = env_blocks ? env_blocks : full ? 4096 : 256;
+  const int gather_ilp = env_ilp ? env_ilp : full ? 8 : 2;
 #define MONO_GATHER(LPR, ILP)                                                                       \
   hipLaunchKernelGGL((k_gather_rows4<LPR, ILP>), dim3(grid_for(n, (256 / LPR) * ILP, gather_blocks)), \
                      dim3(256), 0, gs, t->d, t->cache_slots, n, out)
@@ -2054,10 +2134,13 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
 #undef MONO_GATHER_L
 #undef MONO_GATHER
   MONO_HIP(hipGetLastError());
+  host_tick("lookup: launch gather", &hp);
   // update order beside it
   MONO_HIP(hipStreamWaitEvent(ss, p.ev_probe, 0));
+  host_tick("lookup: ss wait probe", &hp);
   MONO_TRY(sort_pairs_u32(t->cache_slots, p.sslots, nullptr, p.sidx, (size_t)n, end_bit, tmp,
                           tmp_bytes, ss));
+  host_tick("lookup: sort launches", &hp);
   ApplyArgs a{};
   a.skip_slot = kNoSlot;
   a.n = n;
@@ -2069,8 +2152,10 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
   MONO_TRY(queue_setup(&a, p.q_base, n, t->d.dim, &heads, ss, /*counters_cleared=*/true));
   launch_classify(a, long_allowed(t, a.mode, n), heads, ss);
   MONO_HIP(hipGetLastError());
+  host_tick("lookup: classify", &hp);
   p.mode_class = t->last_mode_class;
   MONO_HIP(hipEventRecord(p.ev_ready, ss));
+  host_tick("lookup: record ready", &hp);
   p.chain_pending = true;
 
   p.n = n;
@@ -2087,26 +2172,49 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   *tried = true;
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[0], st));
   // device side: every id was found by the lookup, and the ids are still the same ones
+  double hp = host_prof_on() ? host_now() : 0.0;
   hipLaunchKernelGGL(k_verify, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, st, ids, t->cache_ids, n,
                      p.d_flags, (uint32_t*)p.q_base + 4);
   MONO_HIP(hipGetLastError());
+  host_tick("update: launch verify", &hp);
   MONO_HIP(hipMemcpyAsync(p.h_flags, p.d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  host_tick("update: memcpy flags", &hp);
   MONO_HIP(hipEventRecord(p.ev_verify, st));
+  host_tick("update: record verify", &hp);
   // the count of ids not found restarts here (k_probe only adds to it): behind the read-back, and
   // ahead of the wait for the prepared order, where it costs nothing
   MONO_HIP(hipMemsetAsync(p.d_flags, 0, sizeof(uint32_t), st));
+  host_tick("update: memset flags", &hp);
   MONO_HIP(hipEventSynchronize(p.ev_verify));
+  host_tick("update: sync verify (incl. GPU wait)", &hp);
   const bool changed = p.h_flags[1] != p.seen_changed;
   p.seen_changed = p.h_flags[1];
   if (p.h_flags[0] != 0 || changed) {  // unknown ids to insert, or other ids: full path
     p.n = 0;  // (and never again from this order: the miss count has just been reset)
     return 0;
   }
+  // was the prepared order already complete? (see lookup_prepared: the row gather's throttle)
+  bool slack = false;
+  {
+    slack = hipEventQuery(p.ev_ready) == hipSuccess;
+    (void)hipGetLastError();  // "not ready" is an answer, not an error to find later
+    host_tick("update: query ready", &hp);
+    if (p.full_backoff > 0) --p.full_backoff;
+    if (!p.gather_full) {
+      p.slack_run = slack ? p.slack_run + 1 : 0;
+      if (p.slack_run >= 4 && p.full_backoff == 0) p.gather_full = true;
+    } else if (!slack) {
+      p.gather_full = false;
+      p.slack_run = 0;
+      p.full_backoff = p.full_backoff_len;
+      p.full_backoff_len = std::min(p.full_backoff_len * 2, 4096);
+    }
+  }
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
   const bool classified = p.mode_class == mode_class(mode);
   // a prepared classification is consumed as it is: both apply streams wait for the prepared
   // order themselves (launch_apply); otherwise this stream waits here and classifies again
-  if (!classified || t->profile) MONO_HIP(hipStreamWaitEvent(st, p.ev_ready, 0));
+  if ((!classified || t->profile) && !slack) MONO_HIP(hipStreamWaitEvent(st, p.ev_ready, 0));
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[2], st));
 
   ApplyArgs a{};
@@ -2124,7 +2232,7 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   // (prepared classification: its counters stand; k_verify has reset the hand-out cursor)
   MONO_TRY(queue_setup(&a, p.q_base, n, t->d.dim, &heads, st, /*counters_cleared=*/classified));
   MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st, classified,
-                        classified && !t->profile ? p.ev_ready : nullptr));
+                        classified && !t->profile && !slack ? p.ev_ready : nullptr));
   p.chain_pending = false;  // the caller's stream has waited for ev_ready on every path above
   if (!classified) p.mode_class = mode_class(mode);  // the queues now hold this class
   MONO_HIP(hipGetLastError());
@@ -2385,6 +2493,75 @@ int segment_set_sum_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n,
   MONO_TRY(queue_setup(&a, (char*)t->ws.ptr, n, D, &heads, st));
   MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st));
   MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+// The same sum with the classification done ahead of time (F2 gradient planned by F1, ops.hip):
+// segment_plan_classify runs k_classify on the sorted (float offset, occurrence) pairs into
+// `q_base` (segment_plan_bytes(n, D) bytes) on any stream; segment_set_sum_planned later launches
+// only the apply kernels, which wait for `ready` themselves. out[key .. key + D) is SET, not added
+// to: the caller zero-fills whatever no key covers.
+size_t segment_plan_bytes(int64_t n, int D) { return (queue_bytes(n, D) + 255) & ~(size_t)255; }
+
+static Table* segment_ctx(float* out, int D, bool aligned4) {
+  static Table ctx;
+  Table* t = &ctx;
+  t->d = TableDev{};
+  t->d.rows = out;
+  t->d.dim = D;
+  t->d.row_floats = 1;
+  t->d.n_seg = 1;
+  t->d.seg[0].dim = D;
+  t->d.seg[0].opt_kind = MONO_OPT_SGD;
+  t->d.seg[0].st_off = D;
+  t->opt_tmpl = OPTK_SGD;
+  t->vec = 1;
+  if (aligned4) t->vec = D % 32 == 0 ? 4 : D % 16 == 0 ? 2 : 1;
+  return t;
+}
+
+int segment_plan_classify(const uint32_t* skeys, const uint32_t* sidx, int64_t n, int D, char* q_base,
+                          hipStream_t st) {
+  if (n == 0) return 0;
+  MONO_REQUIRE(D > 0 && D <= kTileFloats, "segment_plan_classify: dim %d exceeds %d", D, kTileFloats);
+  Table* t = segment_ctx(nullptr, D, false);
+  ApplyArgs a{};
+  a.skip_slot = kNoSlot;
+  a.skeys = skeys;
+  a.sidx = sidx;
+  a.n = n;
+  a.mode = MODE_SET_SUM;
+  a.sort_err = sort_error_word();
+  uint4* heads = nullptr;
+  MONO_TRY(queue_setup(&a, q_base, n, D, &heads, st));
+  launch_classify(a, long_allowed(t, a.mode, n), heads, st);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int segment_set_sum_planned(const uint32_t* skeys, const uint32_t* sidx, int64_t n, const float* src,
+                            int D, bool aligned4, float* out, char* q_base, hipEvent_t ready,
+                            hipStream_t st) {
+  if (n == 0) return 0;
+  Table* t = segment_ctx(out, D, aligned4);
+  ApplyArgs a{};
+  a.skip_slot = kNoSlot;
+  a.skeys = skeys;
+  a.sidx = sidx;
+  a.n = n;
+  a.src = src;
+  a.mode = MODE_SET_SUM;
+  a.sort_err = sort_error_word();
+  uint4* heads = nullptr;
+  MONO_TRY(queue_setup(&a, q_base, n, D, &heads, st, /*counters_cleared=*/true));
+  // the long queue's hand-out cursor restarts (a plan may be applied more than once)
+  double hp = host_prof_on() ? host_now() : 0.0;
+  MONO_HIP(hipMemsetAsync(a.qcount + 4, 0, sizeof(uint32_t), st));
+  host_tick("planned: memset cursor", &hp);
+  MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st, /*classified=*/true, ready, /*ready_old=*/true));
+  host_tick("planned: launch_apply total", &hp);
+  MONO_HIP(hipGetLastError());
+  host_tick("planned: get last error", &hp);
   return 0;
 }
 

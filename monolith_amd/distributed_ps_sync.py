@@ -23,6 +23,7 @@ import copy
 import os
 from typing import Callable, Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -87,6 +88,8 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
     self._index = rank
     self._table = table_factory(self._index)
     self._output_dims = self._table.get_table_dim_sizes()
+    self._dims_np = np.asarray(self._output_dims, dtype=np.int64)
+    self._world_size = world
     self._queue_configs = queue_configs or {}  # pipelining queues of the reference: not needed,
     # the exchange is stream-ordered
     if ops is None:
@@ -99,6 +102,8 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
     slot_num = len(slot_to_id)
     sorted_input = [slot_to_id[k] for k in sorted_slot_keys]
     if early_reorder_indicies_res_pack:
+      if hasattr(early_reorder_indicies_res_pack, "result"):  # a reorder still in flight
+        early_reorder_indicies_res_pack = early_reorder_indicies_res_pack.result()
       all_fids, shard_sizes, sharded_slot_sizes, fused_embedding_offsets = \
           early_reorder_indicies_res_pack
     else:
@@ -110,17 +115,23 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
     # The per-(shard, slot) counts travel first (fixed size, K per peer): their row sums are the
     # FID counts every peer is about to send, so the FID exchange needs no size message of its
     # own (one collective and one host synchronisation fewer per step than hvd.alltoall's).
-    shard_sizes_h = torch.as_tensor(shard_sizes).tolist()
-    sss = torch.as_tensor(sharded_slot_sizes, dtype=torch.int32)
-    if _world(self._group)[1] == 1 and not _forced_collective():
-      id_size_flat_h = sss if not sss.is_cuda else sss.cpu()
+    # Host metadata stays in numpy from here on: the GPU is idle until the owner's lookup is
+    # launched, and every torch CPU op on the way costs microseconds.
+    N, K = self._shard_num, slot_num
+    shard_sizes_h = np.asarray(shard_sizes).reshape(-1).tolist()
+    sss_np = np.ascontiguousarray(sharded_slot_sizes, dtype=np.int32).reshape(N, K)
+    single = self._world_size == 1 and not _forced_collective()
+    if single:
+      id_size_np = sss_np
     else:
-      id_size_flat_t, _ = alltoall(sss.to(all_fids.device), [slot_num] * self._shard_num,
-                                   recv_splits=[slot_num] * self._shard_num, group=self._group)
-      id_size_flat_h = id_size_flat_t.cpu()
-    recv_fid_splits = id_size_flat_h.reshape(self._shard_num, slot_num).sum(1).tolist()
+      sss = torch.from_numpy(sss_np.reshape(-1))
+      id_size_flat_t, _ = alltoall(sss.to(all_fids.device), [K] * N, recv_splits=[K] * N,
+                                   group=self._group)
+      id_size_np = id_size_flat_t.cpu().numpy().reshape(N, K)
+    recv_fid_splits = id_size_np.sum(1).tolist()
     id_flat_t, _ = alltoall(all_fids, shard_sizes_h, recv_splits=recv_fid_splits,
                             group=self._group)
+    id_size_flat_h = torch.from_numpy(id_size_np.reshape(-1))
     auxiliary_bundle["shard_sizes"] = shard_sizes
     auxiliary_bundle["fused_embedding_offsets"] = fused_embedding_offsets
     auxiliary_bundle["id_flat_t"] = id_flat_t
@@ -128,23 +139,32 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
 
     # fused_embeddings: [E], embedding_splits: [N], id_offsets / emb_offsets: [K*N]
     fused_embeddings, embedding_splits, id_offsets, emb_offsets, _ = \
-        self._table.fused_lookup(id_flat_t, auxiliary_bundle["id_size_flat_t"], self._shard_num)
+        self._table.fused_lookup(id_flat_t, id_size_np.reshape(-1), self._shard_num)
     auxiliary_bundle["embedding_splits"] = embedding_splits
     auxiliary_bundle["id_offsets"] = id_offsets
     auxiliary_bundle["emb_offsets"] = emb_offsets
-    dims = torch.tensor(self._output_dims, dtype=torch.int32)
-    recv_emb_splits = (sss.reshape(self._shard_num, slot_num) * dims.unsqueeze(0)).sum(1)
+    recv_emb_splits_np = sss_np.astype(np.int64) @ self._dims_np
+    recv_emb_splits = torch.from_numpy(recv_emb_splits_np)
     auxiliary_bundle["recv_emb_splits"] = recv_emb_splits
 
     # recv_embeddings: [E']
     recv_embeddings, _ = alltoall(fused_embeddings, embedding_splits.tolist(),
-                                  recv_splits=recv_emb_splits.tolist(), group=self._group)
+                                  recv_splits=recv_emb_splits_np.tolist(), group=self._group)
     auxiliary_bundle["recv_embeddings_size"] = int(recv_embeddings.numel())
 
     outputs = self._ops.fused_gather_embeddings_by_input(recv_embeddings, fused_embedding_offsets,
                                                          self._output_dims)
     slot_to_embedding = {k: outputs[i] for i, k in enumerate(sorted_slot_keys)}
     return slot_to_embedding, auxiliary_bundle
+
+  def reorder_begin(self, slot_to_id: Dict[str, torch.Tensor]):
+    """Start the reorder of a coming batch (on the current stream, without waiting for it) and
+    return the handle to pass to lookup(..., early_reorder_indicies_res_pack=handle): what the
+    reference's input pipeline does ahead of the step (distributed_ps_sync.py:313-331). One
+    batch ahead at most."""
+    sorted_input = [slot_to_id[k] for k in sorted(slot_to_id.keys())]
+    return self._ops.fused_reorder_by_indices_begin(sorted_input, self._shard_num,
+                                                    self._output_dims)
 
   def assign(self, slot_to_id_and_value):  # "assign is broken" in the reference (:317-321)
     raise NotImplementedError

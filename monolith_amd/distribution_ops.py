@@ -10,6 +10,7 @@ import ctypes as C
 import os
 from typing import List, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from monolith_amd import _lib
@@ -35,6 +36,19 @@ def _i32s(xs):
 
 def _i64s(xs):
   return (C.c_int64 * max(1, len(xs)))(*[int(x) for x in xs])
+
+
+def _flat(x: torch.Tensor, dtype) -> torch.Tensor:
+  """x as a flat contiguous tensor of `dtype`; x itself when it already is one (the hot callers
+  pass such tensors, and every torch call costs microseconds of launch-path host time)."""
+  if x.dtype == dtype and x.dim() == 1 and x.is_contiguous():
+    return x
+  return x.reshape(-1).to(dtype).contiguous()
+
+
+def _host_i32(carr) -> torch.Tensor:
+  """ctypes int32 array -> CPU int32 tensor (own copy)."""
+  return torch.from_numpy(np.ctypeslib.as_array(carr).copy())
 
 
 def _row_ids(id_indices: torch.Tensor) -> torch.Tensor:
@@ -64,31 +78,79 @@ def fused_reorder_by_indices(inputs: List[torch.Tensor], num_of_shards: int,
 
   Returns (output int64[U], shard_sizes int32[N] (host), sharded_slot_sizes int32[N*M] (host),
   fused_embedding_offsets: list of int32 device tensors shaped like the inputs)."""
+  return fused_reorder_by_indices_begin(inputs, num_of_shards, dim_sizes).result()
+
+
+class ReorderHandle:
+  """A fused_reorder_by_indices in flight (fused_reorder_by_indices_begin). result() blocks until
+  the sizes are on the host, makes the current stream wait for the reorder's stream if they
+  differ, and returns what fused_reorder_by_indices returns."""
+
+  def __init__(self, inputs, flat, lens, out_ids, offsets, N, M, stream):
+    self._keep = (inputs, flat)  # the id arrays must outlive the kernels
+    self._lens, self._out_ids, self._offsets, self._N, self._M = lens, out_ids, offsets, N, M
+    self._stream = stream
+    self._done = torch.cuda.Event()
+    self._done.record(stream)
+    self._res = None
+
+  def result(self):
+    if self._res is None:
+      N, M = self._N, self._M
+      shard_sizes = (C.c_int32 * N)()
+      slot_sizes = (C.c_int32 * (N * M))()
+      n_unique = C.c_int64(0)
+      _lib.check(_lib.lib.mono_fused_reorder_finish(C.byref(n_unique), shard_sizes, slot_sizes))
+      cur = torch.cuda.current_stream(self._out_ids.device)
+      if cur != self._stream:
+        cur.wait_event(self._done)
+        for t in [self._out_ids] + self._offsets:
+          t.record_stream(cur)
+      inputs = self._keep[0]
+      offs = PlannedOffsets((o if n > 0 and x.dim() == 1 else o[:n].reshape(x.shape))
+                            for o, n, x in zip(self._offsets, self._lens, inputs))
+      offs.plan_token = int(_lib.lib.mono_fused_reorder_last_plan())
+      self._res = (self._out_ids[:n_unique.value], _host_i32(shard_sizes), _host_i32(slot_sizes),
+                   offs)
+      self._keep = None
+    return self._res
+
+
+def fused_reorder_by_indices_begin(inputs: List[torch.Tensor], num_of_shards: int,
+                                   dim_sizes: List[int]) -> ReorderHandle:
+  """Launch fused_reorder_by_indices on the current stream without waiting for its sizes; the
+  reference computes the reorder ahead of the step in its input pipeline and hands the result
+  to lookup as early_reorder_indicies_res_pack (distributed_ps_sync.py:313-331). One reorder
+  may be in flight at a time: call result() before the next begin."""
   assert len(inputs) == len(dim_sizes) and len(inputs) > 0
   dev = _dev(inputs[0], "fused_reorder_by_indices")
   M, N = len(inputs), int(num_of_shards)
   rank0_empty_shard = os.environ.get("MONOLITH_SYNC_EMPTY_RANK0_PS_SHARD", "1") == "1"
   shard_rule = 1 if (N > 4 and rank0_empty_shard) else 0
-  flat = [x.reshape(-1).to(torch.int64).contiguous() for x in inputs]
-  lens = [int(x.numel()) for x in flat]
+  flat = [_flat(x, torch.int64) for x in inputs]
+  lens = [x.numel() for x in flat]
   total = sum(lens)
   out_ids = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
   offsets = [torch.empty(max(n, 1), dtype=torch.int32, device=dev) for n in lens]
-  shard_sizes = (C.c_int32 * N)()
-  slot_sizes = (C.c_int32 * (N * M))()
-  n_unique = C.c_int64(0)
-  _lib.check(_lib.lib.mono_fused_reorder_by_indices(
-      _ptrs(flat), _i64s(lens), M, N, _i32s(dim_sizes), shard_rule, vp(out_ids),
-      C.byref(n_unique), shard_sizes, slot_sizes, _ptrs(offsets), _lib.stream_ptr(dev)))
-  return (out_ids[:n_unique.value],
-          torch.tensor(list(shard_sizes), dtype=torch.int32),
-          torch.tensor(list(slot_sizes), dtype=torch.int32),
-          [o[:n].reshape(x.shape) for o, n, x in zip(offsets, lens, inputs)])
+  stream = torch.cuda.current_stream(dev)
+  _lib.check(_lib.lib.mono_fused_reorder_begin(
+      _ptrs(flat), _i64s(lens), M, N, _i32s(dim_sizes), shard_rule, vp(out_ids), _ptrs(offsets),
+      C.c_void_p(stream.cuda_stream)))
+  return ReorderHandle(inputs, flat, lens, out_ids, offsets, N, M, stream)
+
+
+class PlannedOffsets(list):
+  """fused_embedding_offsets as fused_reorder_by_indices returns them: a list of int32 tensors
+  that also carries the token of the summation order the library prepared for their gradient
+  (include/monolith_hip.h, mono_fused_gather_embeddings_by_input_gradient_planned). The token
+  only helps while the tensors are passed on unmodified; a plain list works everywhere too."""
+  plan_token = 0
 
 
 def fused_gather_embeddings_by_input_gradient(fused_embeddings, grads: List[torch.Tensor],
                                               embedding_offsets: List[torch.Tensor],
-                                              embedding_dims: List[int]) -> torch.Tensor:
+                                              embedding_dims: List[int],
+                                              plan_token=None) -> torch.Tensor:
   """distribution_ops.py:512-519 -> ops/map_id_to_embedding_op.cc:294-343. `fused_embeddings`
   only supplies the output length (a tensor or an int). Accumulation order is the input order
   (slot by slot, row by row), i.e. the reference's CPU kernel — deterministic."""
@@ -96,29 +158,38 @@ def fused_gather_embeddings_by_input_gradient(fused_embeddings, grads: List[torc
       else int(fused_embeddings)
   dev = _dev(grads[0], "fused_gather_embeddings_by_input_gradient")
   M = len(grads)
-  gs = [g.to(torch.float32).contiguous() for g in grads]
-  offs = [o.reshape(-1).to(torch.int32).contiguous() for o in embedding_offsets]
-  lens = [int(o.numel()) for o in offs]
+  gs = [g if (g.dtype == torch.float32 and g.is_contiguous()) else g.to(torch.float32).contiguous()
+        for g in grads]
+  offs = [_flat(o, torch.int32) for o in embedding_offsets]
+  lens = [o.numel() for o in offs]
   out = torch.empty(max(fused_len, 1), dtype=torch.float32, device=dev)
-  _lib.check(_lib.lib.mono_fused_gather_embeddings_by_input_gradient(
-      C.c_int64(fused_len), _ptrs(gs), _ptrs(offs), _i64s(lens), _i32s(embedding_dims), M, vp(out),
-      _lib.stream_ptr(dev)))
-  return out[:fused_len]
+  if plan_token is None:
+    plan_token = getattr(embedding_offsets, "plan_token", 0)
+  _lib.check(_lib.lib.mono_fused_gather_embeddings_by_input_gradient_planned(
+      C.c_int64(plan_token), C.c_int64(fused_len), _ptrs(gs), _ptrs(offs), _i64s(lens),
+      _i32s(embedding_dims), M, vp(out), _lib.stream_ptr(dev)))
+  return out if fused_len == out.numel() else out[:fused_len]
+
+
+def _fused_gather_forward(fused, dims, offsets):
+  dev = _dev(fused, "fused_gather_embeddings_by_input")
+  fused_c = _flat(fused, torch.float32)
+  offs = [_flat(o, torch.int32) for o in offsets]
+  lens = [o.numel() for o in offs]
+  outs = [torch.empty((n, d), dtype=torch.float32, device=dev) for n, d in zip(lens, dims)]
+  _lib.check(_lib.lib.mono_fused_gather_embeddings_by_input(
+      vp(fused_c), C.c_int64(fused_c.numel()), _ptrs(offs), _i64s(lens), _i32s(dims), len(offs),
+      _ptrs(outs), _lib.stream_ptr(dev)))
+  return fused_c, offs, outs
 
 
 class _FusedGather(torch.autograd.Function):
 
   @staticmethod
-  def forward(ctx, fused, dims, *offsets):
-    dev = _dev(fused, "fused_gather_embeddings_by_input")
-    fused_c = fused.to(torch.float32).contiguous()
-    offs = [o.reshape(-1).to(torch.int32).contiguous() for o in offsets]
-    lens = [int(o.numel()) for o in offs]
-    outs = [torch.empty((n, d), dtype=torch.float32, device=dev) for n, d in zip(lens, dims)]
-    _lib.check(_lib.lib.mono_fused_gather_embeddings_by_input(
-        vp(fused_c), C.c_int64(fused_c.numel()), _ptrs(offs), _i64s(lens), _i32s(dims), len(offs),
-        _ptrs(outs), _lib.stream_ptr(dev)))
+  def forward(ctx, fused, dims, plan_token, *offsets):
+    fused_c, offs, outs = _fused_gather_forward(fused, dims, offsets)
     ctx.dims = list(dims)
+    ctx.plan_token = plan_token
     ctx.fused_len = int(fused_c.numel())
     ctx.save_for_backward(*offs)
     return tuple(outs)
@@ -126,8 +197,9 @@ class _FusedGather(torch.autograd.Function):
   @staticmethod
   def backward(ctx, *grads):
     offs = ctx.saved_tensors
-    g = fused_gather_embeddings_by_input_gradient(ctx.fused_len, list(grads), list(offs), ctx.dims)
-    return (g, None) + (None,) * len(offs)
+    g = fused_gather_embeddings_by_input_gradient(ctx.fused_len, list(grads), list(offs), ctx.dims,
+                                                  ctx.plan_token)
+    return (g, None, None) + (None,) * len(offs)
 
 
 def fused_gather_embeddings_by_input(fused_embeddings: torch.Tensor,
@@ -135,7 +207,12 @@ def fused_gather_embeddings_by_input(fused_embeddings: torch.Tensor,
                                      embedding_dims: List[int]) -> List[torch.Tensor]:
   """distribution_ops.py:505-509 -> ops/map_id_to_embedding_op.cc:239-292: slot m's output row i
   is fused_embeddings[offset_m[i] : offset_m[i] + dim_m]."""
-  return list(_FusedGather.apply(fused_embeddings, list(embedding_dims), *fused_embedding_offsets))
+  if not (fused_embeddings.requires_grad and torch.is_grad_enabled()):
+    # nothing to differentiate (the sync-training path calls the gradient op itself)
+    return _fused_gather_forward(fused_embeddings, list(embedding_dims), fused_embedding_offsets)[2]
+  return list(_FusedGather.apply(fused_embeddings, list(embedding_dims),
+                                 getattr(fused_embedding_offsets, "plan_token", 0),
+                                 *fused_embedding_offsets))
 
 
 # ----------------------------------------------------------------------------- pooling

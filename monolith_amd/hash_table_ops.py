@@ -31,12 +31,16 @@ def _ids(x) -> torch.Tensor:
   """`ids = tf.convert_to_tensor(ids, tf.int64)` (hash_table_ops.py:254)."""
   if not isinstance(x, torch.Tensor):
     x = torch.as_tensor(x, dtype=torch.int64)
+  elif x.is_cuda and x.dtype == torch.int64 and x.dim() == 1 and x.is_contiguous():
+    return x  # (the hot callers: no torch call on the launch path)
   return x.to(device=_dev(), dtype=torch.int64).reshape(-1).contiguous()
 
 
 def _f32(x) -> torch.Tensor:
   if not isinstance(x, torch.Tensor):
     x = torch.as_tensor(x, dtype=torch.float32)
+  elif x.is_cuda and x.dtype == torch.float32 and x.is_contiguous():
+    return x
   return x.to(device=_dev(), dtype=torch.float32).contiguous()
 
 
@@ -440,6 +444,16 @@ def restore_hash_tables(asset_dir: str, tables: Sequence[HashTable]) -> None:
                        "structure has been changed." % (asset_dir, prefixes))
 
 
+def _host_np(x, dtype) -> np.ndarray:
+  """Host metadata (tensor / list / ndarray, possibly a list of 0-d tensors) as a flat contiguous
+  numpy array."""
+  if isinstance(x, torch.Tensor):
+    x = x.detach().cpu().numpy()
+  elif isinstance(x, (list, tuple)) and x and isinstance(x[0], torch.Tensor):
+    x = [float(v) for v in x]
+  return np.ascontiguousarray(x, dtype=dtype).reshape(-1)
+
+
 def _handles(tables):
   res = [t.table if isinstance(t, HashTable) else t for t in tables]
   return res, (C.c_void_p * len(res))(*[r.h.value for r in res])
@@ -487,18 +501,19 @@ def fused_apply_gradient(tables: List, ids, fused_slot_size, id_grads, id_offset
   K, N = len(res), int(num_of_shards)
   ids = _ids(ids)
   grads = _f32(id_grads).reshape(-1)
-  fss = torch.as_tensor(fused_slot_size, dtype=torch.int32).cpu().contiguous()
-  io = torch.as_tensor(id_offsets, dtype=torch.int32).cpu().contiguous()
-  go = torch.as_tensor(grad_offsets, dtype=torch.int32).cpu().contiguous()
-  lrs = torch.as_tensor(learning_rate_tensors, dtype=torch.float32).cpu().contiguous()
-  lrl = torch.as_tensor(learning_rate_lengths, dtype=torch.int32).cpu().contiguous()
-  if fss.numel() != K * N:
+  # host metadata in numpy: a torch CPU op costs microseconds each on the launch path
+  fss = _host_np(fused_slot_size, np.int32)
+  io = _host_np(id_offsets, np.int32)
+  go = _host_np(grad_offsets, np.int32)
+  lrs = _host_np(learning_rate_tensors, np.float32)
+  lrl = _host_np(learning_rate_lengths, np.int32)
+  if fss.size != K * N:
     raise _lib.MonolithHipError("len(fused_slot_size) / num_of_shards != len(table_handles)")
   fs = (C.c_void_p * K)(*[(r.filter.handle.value if r.filter is not None else None) for r in res])
   _lib.check(_lib.lib.mono_tables_fused_apply_gradient(
-      hs, fs, C.c_int(K), _lib.vp(ids), C.c_void_p(fss.data_ptr()), _lib.vp(grads),
-      C.c_void_p(io.data_ptr()), C.c_void_p(go.data_ptr()), C.c_void_p(lrs.data_ptr()),
-      C.c_void_p(lrl.data_ptr()), C.c_int64(_scalar(req_time)), C.c_int64(_scalar(global_step)),
+      hs, fs, C.c_int(K), _lib.vp(ids), C.c_void_p(fss.ctypes.data), _lib.vp(grads),
+      C.c_void_p(io.ctypes.data), C.c_void_p(go.ctypes.data), C.c_void_p(lrs.ctypes.data),
+      C.c_void_p(lrl.ctypes.data), C.c_int64(_scalar(req_time)), C.c_int64(_scalar(global_step)),
       C.c_int(N), C.c_int(int(bool(enable_grad_accumulation))), _lib.stream_ptr()))
   for k, t in enumerate(tables):
     if isinstance(t, HashTable) and t.table.touched_key_set is not None:

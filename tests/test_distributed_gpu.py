@@ -172,3 +172,44 @@ def test_world1_exchange_over_rccl():
   rank, err = q.get(timeout=150)
   p.join(timeout=30)
   assert err is None, "rccl world-1 run failed:\n%s" % err
+
+
+def test_reorder_one_batch_ahead_on_a_side_stream():
+  """fused_reorder_by_indices_begin on a side stream while another batch is looked up and
+  updated on the main stream (bench.py's pipelined step): the pack handed to lookup as
+  early_reorder_indicies_res_pack gives the rows and the table state of the in-line order."""
+  from monolith_amd import distributed_ps_sync, entry, hash_table_ops, multi_type_hash_table
+  dev = torch.device("cuda", 0)
+
+  def build(tag):
+    tc = entry.EmbeddingHashTableConfig(
+        segments=[entry.CombineAsSegment(16, entry.ZerosInitializer(),
+                                         entry.AdagradOptimizer(initial_accumulator_value=0.1))],
+        initial_capacity=1 << 16, seed=5)
+    cfgs = {"s": entry.HashTableConfigInstance(tc, [0.05])}
+    fac = lambda idx: multi_type_hash_table.MultiTypeHashTable(
+        cfgs, lambda slot, c: hash_table_ops.hash_table_from_config(c, name_suffix="%s_%s" % (tag, slot)))
+    return distributed_ps_sync.DistributedMultiTypeHashTableMpi(1, fac)
+
+  rng = np.random.Generator(np.random.PCG64(77))
+  batches = [torch.tensor((3000 * rng.random(40000) ** 3).astype(np.int64) * 7919, device=dev)
+             for _ in range(5)]
+  grads = [torch.tensor(rng.normal(0, 0.1, (40000, 16)).astype(np.float32), device=dev)
+           for _ in range(5)]
+  outs = {}
+  for mode in ("inline", "ahead"):
+    t = build(mode)
+    side = torch.cuda.Stream(dev)
+    pack, res = None, []
+    for i, (b, g) in enumerate(zip(batches, grads)):
+      emb, bundle = t.lookup({"s": b}, {}, early_reorder_indicies_res_pack=pack)
+      pack = None
+      if mode == "ahead" and i + 1 < len(batches):
+        with torch.cuda.stream(side):
+          pack = t.reorder_begin({"s": batches[i + 1]})
+      res.append(emb["s"].clone())
+      t = t.apply_gradients({"s": (b, g)}, bundle, global_step=i, req_time=100 + i)
+    torch.cuda.synchronize()
+    outs[mode] = [r.cpu().numpy() for r in res]
+  for a, b in zip(outs["inline"], outs["ahead"]):
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))

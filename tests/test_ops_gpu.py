@@ -139,6 +139,46 @@ def test_fused_gather_and_gradient(ops):
 
 
 # ----------------------------------------------------------------------------- pooling
+@pytest.mark.parametrize("dims", [[16], [64], [8, 3, 16], [4, 4, 4]])
+def test_gather_gradient_planned_by_reorder(ops, dims):
+  """The summation order fused_reorder_by_indices prepares for the gradient of the gather (the
+  token on its offsets) gives the unplanned result, bit for bit: hot ids (thousands of
+  occurrences: the long-segment kernels), several slots, mixed dims, a fused buffer longer than
+  the rows the ids cover (tail zero-filled), a plan used twice, and a plan displaced by two later
+  reorders (falls back to the unplanned path)."""
+  d_ops = ops[0]
+  rng = np.random.Generator(np.random.PCG64(1234 + sum(dims)))
+  M = len(dims)
+  lens = [60000, 17, 9000][:M] if M > 1 else [150000]
+  inputs = []
+  for m, n in enumerate(lens):
+    # a Zipf-like head: the hottest id has ~2500 occurrences (the long-segment kernels; below the
+    # 4096 of the chunked sum, whose reassociation DESIGN.md 4.1 documents)
+    x = (200000 * rng.random(n) ** 3).astype(np.int64)
+    inputs.append(x * 1000003 + m)
+  ids_t = [T(x, torch.int64) for x in inputs]
+  o, s, ss, offs = d_ops.fused_reorder_by_indices(ids_t, 2, dims)
+  assert getattr(offs, "plan_token", 0) != 0
+  covered = int(sum(int(c) * dims[i % M] for i, c in enumerate(ss.tolist())))
+  grads = [rng.normal(0, 0.1, (n, d)).astype(np.float32) for n, d in zip(lens, dims)]
+  g_t = [T(g, torch.float32) for g in grads]
+  offs_np = [x.cpu().numpy().reshape(-1) for x in offs]
+  for fused_len in (covered, covered + 40):
+    exp = cpu.fused_gather_embeddings_by_input_gradient(fused_len, grads, offs_np, dims)
+    planned = d_ops.fused_gather_embeddings_by_input_gradient(fused_len, g_t, offs, dims)
+    again = d_ops.fused_gather_embeddings_by_input_gradient(fused_len, g_t, offs, dims)
+    plain = d_ops.fused_gather_embeddings_by_input_gradient(fused_len, g_t, list(offs), dims)
+    assert np.array_equal(bits(planned), bits(exp))
+    assert np.array_equal(bits(again), bits(exp))
+    assert np.array_equal(bits(plain), bits(exp))
+  # two more reorders displace the plan: the stale token is ignored
+  for _ in range(2):
+    d_ops.fused_reorder_by_indices([T(inputs[0][:100], torch.int64)], 2, [dims[0]])
+  stale = d_ops.fused_gather_embeddings_by_input_gradient(covered, g_t, offs, dims)
+  exp = cpu.fused_gather_embeddings_by_input_gradient(covered, grads, offs_np, dims)
+  assert np.array_equal(bits(stale), bits(exp))
+
+
 def test_combiners_reference_vectors(ops):
   """embedding_combiners_test.py:22-35."""
   _, comb, _ = ops
