@@ -165,17 +165,25 @@ def main_sharded(args, rank, world, device):
   # The reorder of batch i + 1 is issued on a side stream while step i runs, as the reference's
   # input pipeline does (distributed_ps_sync.py:313-331, early_reorder_indicies_res_pack): every
   # step still does one reorder, one lookup and one update; --no-prefetch keeps them in line.
-  side = torch.cuda.Stream(device) if not args.no_prefetch else None
+  side = not args.no_prefetch
+  where = os.environ.get("MONO_BENCH_PREFETCH_AT", "lookup")  # experiment: start | lookup | grad
+  side_stream = torch.cuda.Stream(device) if side else None
 
   def step(i):
     ids = {"criteo": pool[i % n_pool]}
-    pack = state.pop("pack", None)
+    nxt = {"criteo": pool[(i + 1) % n_pool]} if side else None
+    pack = state.pop("pack", None) or state["t"].take_prefetched_reorder()
+    if side and where == "start":
+      pack = (pack if pack is not None else state["t"].reorder_begin(ids)).result()
+      with torch.cuda.stream(side_stream):
+        state["pack"] = state["t"].reorder_begin(nxt)
     emb, bundle = state["t"].lookup(ids, auxiliary_bundle={}, early_reorder_indicies_res_pack=pack)
-    if side is not None:
-      with torch.cuda.stream(side):
-        state["pack"] = state["t"].reorder_begin({"criteo": pool[(i + 1) % n_pool]})
+    if side and where == "lookup":
+      with torch.cuda.stream(side_stream):
+        state["pack"] = state["t"].reorder_begin(nxt)
     state["t"] = state["t"].apply_gradients({"criteo": (ids["criteo"], grad)}, bundle,
-                                            global_step=i, req_time=10 + i)
+                                            global_step=i, req_time=10 + i,
+                                            next_slot_to_id=nxt if where == "grad" else None)
     return emb
 
   def barrier():
@@ -218,7 +226,7 @@ def main_sharded(args, rank, world, device):
                                                           world, D, args.batch, args.backend),
                  "fids_per_step_per_gpu": n, "unique_ratio_per_rank": uniq, "skew": args.skew,
                  "parallelism": "table sharded over %d GPUs, all-to-all exchange" % world,
-                 "reorder": "one batch ahead on a side stream" if side is not None else "in line",
+                 "reorder": "one batch ahead on a side stream" if side else "in line",
                  "populate_s": t_pop, "table_rows": total_rows},
       "roofline": {"bound": "hbm", "kernel": "whole step (per GPU)", "achieved": step_gbs,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,

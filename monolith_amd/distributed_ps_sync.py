@@ -90,6 +90,8 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
     self._output_dims = self._table.get_table_dim_sizes()
     self._dims_np = np.asarray(self._output_dims, dtype=np.int64)
     self._world_size = world
+    self._side_stream = None
+    self._prefetched = None
     self._queue_configs = queue_configs or {}  # pipelining queues of the reference: not needed,
     # the exchange is stream-ordered
     if ops is None:
@@ -173,10 +175,16 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
     raise NotImplementedError
 
   def apply_gradients(self, slot_to_id_and_grad: Dict[str, Tuple[torch.Tensor, torch.Tensor]],
-                      auxiliary_bundle: Dict, global_step, req_time=None):
+                      auxiliary_bundle: Dict, global_step, req_time=None, next_slot_to_id=None):
     """Fused update (distributed_ps_sync.py:330-521). Gradient rows of one FID coming from
     different ranks stay separate entries of the owner's id list and are applied as separate
-    optimizer steps in source-shard-major order."""
+    optimizer steps in source-shard-major order.
+
+    next_slot_to_id: the ids of the NEXT batch, if the caller has them (the reference's input
+    pipeline does: early_reorder_indicies_res_pack, :313-331). Their reorder is then issued on a
+    side stream at the point of this call where the launches cost the step nothing — behind the
+    gradient kernels, ahead of the update's wait — and the handle is kept for
+    take_prefetched_reorder()."""
     if req_time is None:
       req_time = 0
     sorted_slot_keys = sorted(slot_to_id_and_grad.keys())
@@ -192,12 +200,26 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
     grad_flat_t, _ = alltoall(grad_flat, recv_emb_splits.tolist(),
                               recv_splits=embedding_splits.tolist(), group=self._group)
     auxiliary_bundle.pop("shard_sizes")
+    prefetched = None
+    if next_slot_to_id is not None:
+      if self._side_stream is None:
+        self._side_stream = torch.cuda.Stream(grad_flat.device)
+      with torch.cuda.stream(self._side_stream):
+        prefetched = self.reorder_begin(next_slot_to_id)
 
     updated_table = self._table.fused_apply_gradient(
         auxiliary_bundle.pop("id_flat_t"), auxiliary_bundle.pop("id_size_flat_t"), grad_flat_t,
         auxiliary_bundle.pop("id_offsets"), auxiliary_bundle.pop("emb_offsets"), global_step,
         req_time, self._shard_num)
-    return self._copy_with_new_table(updated_table)
+    updated = self._copy_with_new_table(updated_table)
+    updated._prefetched = prefetched
+    return updated
+
+  def take_prefetched_reorder(self):
+    """The reorder apply_gradients(next_slot_to_id=...) started, for lookup's
+    early_reorder_indicies_res_pack (None if there is none)."""
+    pack, self._prefetched = self._prefetched, None
+    return pack
 
   def as_op(self, name=None):
     return self._table.as_op(name)

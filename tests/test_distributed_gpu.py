@@ -199,16 +199,13 @@ def test_reorder_one_batch_ahead_on_a_side_stream():
   outs = {}
   for mode in ("inline", "ahead"):
     t = build(mode)
-    side = torch.cuda.Stream(dev)
-    pack, res = None, []
+    res = []
     for i, (b, g) in enumerate(zip(batches, grads)):
-      emb, bundle = t.lookup({"s": b}, {}, early_reorder_indicies_res_pack=pack)
-      pack = None
-      if mode == "ahead" and i + 1 < len(batches):
-        with torch.cuda.stream(side):
-          pack = t.reorder_begin({"s": batches[i + 1]})
+      emb, bundle = t.lookup({"s": b}, {}, early_reorder_indicies_res_pack=t.take_prefetched_reorder())
       res.append(emb["s"].clone())
-      t = t.apply_gradients({"s": (b, g)}, bundle, global_step=i, req_time=100 + i)
+      nxt = {"s": batches[i + 1]} if mode == "ahead" and i + 1 < len(batches) else None
+      t = t.apply_gradients({"s": (b, g)}, bundle, global_step=i, req_time=100 + i,
+                            next_slot_to_id=nxt)
     torch.cuda.synchronize()
     outs[mode] = [r.cpu().numpy() for r in res]
   for a, b in zip(outs["inline"], outs["ahead"]):
