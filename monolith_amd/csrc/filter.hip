@@ -2,6 +2,7 @@
 // Reference: runtime/neo_filter/{hash_filter.h,sliding_hash_filter.{h,cc},dummy_hash_filter.h},
 // ops/neo_filter_tf_bridge.cc:25-40, ops/hash_filter_op.cc:109-141,
 // ops/hash_filter_intercept_gradient_op.cc:39-62.
+#include <algorithm>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 #include <vector>
@@ -26,7 +27,8 @@ int filter_dev_view(void* filter, FilterDev* out, hipStream_t) {
   return 0;
 }
 
-// sliding_hash_filter.cc:83-87, applied at the batch boundary: one rotation at most per batch.
+// sliding_hash_filter.cc:83-87, applied at the batch boundary (one rotation per launch pair;
+// filter_after_batch repeats the pair as often as the batch could have filled blocks).
 __global__ void k_filter_rotate_decide(FilterDev f) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   uint32_t head = f.state[0];
@@ -54,12 +56,23 @@ __global__ void __launch_bounds__(256) k_filter_rotate_clear(FilterDev f) {
   if (blockIdx.x == 0 && threadIdx.x < kFilterShards) *filter_counter(f, blk, threadIdx.x) = 0;
 }
 
-int filter_after_batch(void* filter, hipStream_t st) {
+// `new_ids`: an upper bound of the ids the batch may have added. A batch can fill the head block
+// and spill into the next one (filter_add looks forward over two blocks); each decide/clear pair
+// rotates once if the (new) head is full, so the pair runs once per block the batch could have
+// filled, and the next batch never starts on a full head. (A single batch that overflows BOTH
+// blocks it can reach still sees failed adds inside the batch — the reference rotates in the
+// middle of its stream — which the gate admits and failure_count records: DESIGN.md deviation 2.)
+int filter_after_batch(void* filter, hipStream_t st, int64_t new_ids) {
   Filter* f = (Filter*)filter;
   if (f->kind != 1) return 0;
-  hipLaunchKernelGGL(k_filter_rotate_decide, dim3(1), dim3(64), 0, st, f->d);
-  hipLaunchKernelGGL(k_filter_rotate_clear, dim3(grid_for((int64_t)f->d.stride, 256, 2048)),
-                     dim3(256), 0, st, f->d);
+  int64_t rounds = 1;
+  if (new_ids > 0 && f->d.capacity > 0) rounds = 1 + new_ids / (int64_t)f->d.capacity;
+  rounds = std::min<int64_t>(rounds, std::max<int64_t>(1, (int64_t)f->d.n_blocks - 1));
+  for (int64_t r = 0; r < rounds; ++r) {
+    hipLaunchKernelGGL(k_filter_rotate_decide, dim3(1), dim3(64), 0, st, f->d);
+    hipLaunchKernelGGL(k_filter_rotate_clear, dim3(grid_for((int64_t)f->d.stride, 256, 2048)),
+                       dim3(256), 0, st, f->d);
+  }
   MONO_HIP(hipGetLastError());
   return 0;
 }
@@ -140,7 +153,7 @@ static int batch_add(Filter* f, const int64_t* ids, const int32_t* counts, int64
   hipLaunchKernelGGL(k_filter_batch_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f->d,
                      key_out, idx_out, n, counts, respect_threshold, old_out);
   MONO_HIP(hipGetLastError());
-  return filter_after_batch(f, st);
+  return filter_after_batch(f, st, n);
 }
 
 }  // namespace mono

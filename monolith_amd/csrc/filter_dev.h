@@ -35,7 +35,7 @@ struct FilterDev {
 
 // Host side (filter.hip)
 int filter_dev_view(void* filter, FilterDev* out, hipStream_t st);
-int filter_after_batch(void* filter, hipStream_t st);
+int filter_after_batch(void* filter, hipStream_t st, int64_t new_ids = 0);
 
 constexpr int kFilterMaxStep = 16;  // sliding_hash_filter.h:98
 constexpr int kFilterShards = 64;   // counter shards per block, each on a cache line of its own

@@ -2329,7 +2329,7 @@ static int write_path_gated(Table* t, void* filter, ApplyArgs a, const int64_t* 
     MONO_HIP(hipGetLastError());
   }
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
-  return filter_after_batch(filter, st);
+  return filter_after_batch(filter, st, U);
 }
 
 // The whole write path. `filter` gates inserts of unknown ids (nullptr / dummy = no gate).
@@ -2414,7 +2414,7 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st));
   MONO_HIP(hipGetLastError());
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
-  if (from_keys) MONO_TRY(filter_after_batch(filter, st));
+  if (from_keys) MONO_TRY(filter_after_batch(filter, st, n));
   return 0;
 }
 

@@ -330,6 +330,29 @@ def test_filter_rotation_replayed_per_id(ops):
   assert sh["head"] == so["head"] and sh["num_elements"] == so["num_elements"]
 
 
+def test_filter_rotates_past_every_block_a_batch_filled(ops):
+  """One batch far above a block's capacity (sliding filter of 10 blocks x ~333 ids, 700 new
+  ids at once): the head block and the one after it both fill inside the batch, and the
+  batch-end rotation is repeated until the head is a block with room — the next batch must not
+  start on a full head, and adds without failures. (Inside the oversized batch the adds are
+  spread over the two blocks filter_add can reach and the overflow fails, which failure_count
+  records; the reference rotates in mid-stream instead: DESIGN.md deviation 2.)"""
+  from monolith_amd.entry import SlotOccurrenceThresholdConfig
+  hf = ops[2]
+  f = hf.create_hash_filter(3000, 10, SlotOccurrenceThresholdConfig(default_occurrence_threshold=2))
+  rng = np.random.Generator(np.random.PCG64(31))
+  big = (rng.permutation(1 << 20)[:700].astype(np.int64) << 17) + 5
+  hf.intercept_gradient_gradient(f, T(big, torch.int64), torch.ones((700, 2), device=dev()))
+  st1 = f.state()
+  assert st1["head_increment"] >= 1, st1
+  fails = st1["failure_count"]
+  small = (rng.permutation(1 << 20)[:40].astype(np.int64) << 17) + 9
+  hf.intercept_gradient_gradient(f, T(small, torch.int64), torch.ones((40, 2), device=dev()))
+  st2 = f.state()
+  assert st2["failure_count"] == fails, (st1, st2)
+  assert sum(st2["num_elements"]) == sum(st1["num_elements"]) + 40, (st1, st2)
+
+
 def test_filter_random_counts_vs_oracle(ops):
   """Batched add / get on ids with distinct signatures: old counts equal the sequential oracle."""
   hf = ops[2]
