@@ -278,32 +278,6 @@ __global__ void __launch_bounds__(256) k_layout_grad_enumerate(GradArgs a) {
   }
 }
 
-// One 8-lane sub-group per sorted position; the head of a segment walks it in order
-// (first touch copies, later touches add: OptimizedSumpooling, :385-400).
-__global__ void __launch_bounds__(256) k_layout_grad_apply(GradArgs a, const uint32_t* skey,
-                                                           const uint32_t* sidx) {
-  const int sub = threadIdx.x & 7;
-  const long long j = (long long)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
-  if (j >= a.n_contrib) return;
-  const uint32_t key = skey[j];
-  if (key == a.nokey) return;
-  if (j > 0 && skey[j - 1] == key) return;
-  const int dim = a.l.slices[a.cslice[sidx[j]]].dim;
-  // destination: the buffer whose [gbase, gbase + floats) holds `key`
-  int lo = 0, hi = a.l.n_bufs - 1;
-  while (lo < hi) {
-    int mid = (lo + hi + 1) >> 1;
-    if (a.l.bufs[mid].gbase <= (long long)key) lo = mid; else hi = mid - 1;
-  }
-  float* dst = a.l.bufs[lo].ptr + ((long long)key - a.l.bufs[lo].gbase);
-  for (int k = sub; k < dim; k += 8) {
-    float acc = a.srcp[sidx[j]][k];
-    for (long long p = j + 1; p < a.n_contrib && skey[p] == key; ++p)
-      acc = a.srcp[sidx[p]][k] + acc;
-    dst[k] = acc;
-  }
-}
-
 static int bits_for_l(uint64_t max_value) {
   int b = 1;
   while (b < 64 && (max_value >> b) != 0) ++b;

@@ -8,4 +8,5 @@ for c in 3 4 5; do
   timeout -k 10 280 python3 bench.py --config $c > $O/${T}_c${c}_bench.json 2> $O/${T}_c${c}_bench.err
   scripts/prof_config.sh ${T}_c${c}_prof --config $c --steps 10 --warmup 3 > $O/${T}_c${c}_top.txt
 done
-timeout -k 10 280 python3 bench.py --sharded --no-cpu > $O/${T}_sharded_n1_bench.json 2> $O/${T}_sharded_n1_bench.err
+scripts/prof_sharded.sh ${T}_sharded_n1 --sharded > $O/${T}_sharded_n1_top.txt
+scripts/prof_sharded.sh ${T}_c4_n1 --config 4 > $O/${T}_c4_n1_top.txt
