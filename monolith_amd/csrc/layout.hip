@@ -13,6 +13,7 @@
 // one (unique fid, column range). Contributions are enumerated in the reference's order, keyed
 // by the float offset of their destination, stably sorted by key (sort.hip), and each segment is
 // summed left to right by one 8-lane sub-group — no float atomics, first touch = copy.
+#include <cstring>
 #include <algorithm>
 #include <vector>
 
@@ -43,6 +44,8 @@ struct BufDev {
   // mono_table_lookup would have written), rows `stride` floats apart. nullptr: a dense buffer.
   const uint32_t* slots;
   int stride;
+  long long gbase_u;  // gradient: gbase and dim in units of the destination keys
+  int dim_u;
 };
 constexpr uint32_t kNoSlotL = 0xFFFFFFFFu;
 
@@ -219,6 +222,7 @@ struct GradSliceDev {
   long long cbase;  // first contribution index of the slice
   int p0;           // first fid position of the slice's feature range
   int len0;         // shared: length of the (single) run
+  int start_u;      // the slice's first column, in key units
 };
 
 struct GradArgs {
@@ -226,23 +230,33 @@ struct GradArgs {
   const GradSliceDev* gs;
   const float* const* out_grads;
   long long n_contrib;
-  uint32_t* key;
-  uint32_t* cslice;
-  const float** srcp;
+  uint32_t* key;       // destination, in units of key_unit floats
+  uint32_t* val;       // packed form: slice | sample << sbits | seq << (sbits + bbits)
+  uint32_t* cslice;    // pointer form (the packing does not fit 32 bits): slice of contribution c
+  const float** srcp;  //               ... and its source row; the sort then carries c itself
   uint32_t nokey;  // key of a use that scatters nothing (FIRSTN beyond max_seq); sorts last
+  int key_unit;
+  int packed, sbits, bbits;
 };
 
+// One thread per use. A wave's 64 uses are consecutive fid positions of (nearly always) one
+// slice, so the feature run of the wave's first use is found once, by a search every lane runs on
+// the same values (scalar loads), and each lane walks forward from there: 14 dependent vector
+// loads per use otherwise, which made this kernel as expensive as a sort pass.
 __global__ void __launch_bounds__(256) k_layout_grad_enumerate(GradArgs a) {
-  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < a.n_contrib;
+  const int lane = threadIdx.x & 63;
+  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c - lane < a.n_contrib;
        c += (long long)gridDim.x * blockDim.x) {
+    const bool act = c < a.n_contrib;
+    const long long cc = act ? c : a.n_contrib - 1;
     int lo = 0, hi = a.l.n_slices - 1;
     while (lo < hi) {
       int mid = (lo + hi + 1) >> 1;
-      if (a.gs[mid].cbase <= c) lo = mid; else hi = mid - 1;
+      if (a.gs[mid].cbase <= cc) lo = mid; else hi = mid - 1;
     }
     const SliceDev sc = a.l.slices[lo];
     const GradSliceDev gs = a.gs[lo];
-    const long long local = c - gs.cbase;
+    const long long local = cc - gs.cbase;
     int b, seq, p;
     if (sc.shared) {  // every sample scatters to the one shared run (:874-876)
       b = (int)(local / gs.len0);
@@ -251,31 +265,61 @@ __global__ void __launch_bounds__(256) k_layout_grad_enumerate(GradArgs a) {
     } else {
       p = gs.p0 + (int)local;
       // feature run holding fid position p: last f in [f0, f0 + batch) with feature_offset[f] <= p
-      int flo = sc.f0, fhi = sc.f0 + a.l.batch - 1;
-      while (flo < fhi) {
+      const int lo1 = __builtin_amdgcn_readfirstlane(lo);
+      const int p1 = __builtin_amdgcn_readfirstlane(p);
+      const int f01 = __builtin_amdgcn_readfirstlane(sc.f0);
+      int flo = f01, fhi = f01 + a.l.batch - 1;
+      while (flo < fhi) {  // the first lane's run (uniform)
         int mid = (flo + fhi + 1) >> 1;
-        if (a.l.feature_offset[mid] <= p) flo = mid; else fhi = mid - 1;
+        if (a.l.feature_offset[mid] <= p1) flo = mid; else fhi = mid - 1;
+      }
+      if (lo == lo1) {  // same slice, p >= p1: forward from the first lane's run
+        const int last = sc.f0 + a.l.batch - 1;
+        while (flo < last && a.l.feature_offset[flo + 1] <= p) ++flo;
+      } else {  // a wave that straddles two slices: search on its own
+        flo = sc.f0;
+        fhi = sc.f0 + a.l.batch - 1;
+        while (flo < fhi) {
+          int mid = (flo + fhi + 1) >> 1;
+          if (a.l.feature_offset[mid] <= p) flo = mid; else fhi = mid - 1;
+        }
       }
       b = flo - sc.f0;
       seq = p - a.l.feature_offset[flo];
     }
+    if (!act) continue;
     uint32_t key = a.nokey;
     const float* src = nullptr;
+    const bool firstn = sc.pooling == MONO_POOL_FIRSTN;
     const uint64_t fo = a.l.fid_offset[p];
     const uint32_t i1 = (uint32_t)(fo >> 32), i2 = (uint32_t)fo;
-    if (i1 < (uint32_t)a.l.n_bufs && !(sc.pooling == MONO_POOL_FIRSTN && seq >= sc.max_seq)) {
+    if (i1 < (uint32_t)a.l.n_bufs && !(firstn && seq >= sc.max_seq)) {
       const BufDev bd = a.l.bufs[i1];
       const long long off = (long long)i2 * bd.dim + sc.start;
       if (off + sc.dim <= bd.floats) {
-        key = (uint32_t)(bd.gbase + off);
-        src = a.out_grads[sc.out_index] + (long long)b * sc.out_stride + sc.out_offset +
-              (sc.pooling == MONO_POOL_FIRSTN ? seq * sc.dim : 0);
+        key = (uint32_t)(bd.gbase_u + (long long)i2 * bd.dim_u + gs.start_u);
+        if (!a.packed)
+          src = a.out_grads[sc.out_index] + (long long)b * sc.out_stride + sc.out_offset +
+                (firstn ? seq * sc.dim : 0);
       }
     }
     a.key[c] = key;
-    a.cslice[c] = (uint32_t)lo;
-    a.srcp[c] = src;
+    if (a.packed) {
+      a.val[c] = key == a.nokey ? 0u
+                                : ((uint32_t)lo | ((uint32_t)b << a.sbits) |
+                                   (firstn ? (uint32_t)seq << (a.sbits + a.bbits) : 0u));
+    } else {
+      a.cslice[c] = (uint32_t)lo;
+      a.srcp[c] = src;
+    }
   }
+}
+
+// dst[i] = idx[i] < 0 ? fill : src[idx[i]] (the few feature_offset entries the host needs)
+__global__ void k_pick_i32(const int32_t* __restrict__ src, const int32_t* __restrict__ idx, int n,
+                           int32_t fill, int32_t* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = idx[i] < 0 ? fill : src[idx[i]];
 }
 
 static int bits_for_l(uint64_t max_value) {
@@ -334,7 +378,7 @@ static int build_plan(const mono_layout_slice* h_slices, int n_slices, float* co
   hp->bufs.resize(n_bufs);
   for (int i = 0; i < n_bufs; ++i) {
     hp->bufs[i] = BufDev{emb_ptrs[i], h_emb_dims[i], (long long)h_emb_floats[i], gb, nullptr,
-                         h_emb_dims[i]};
+                         h_emb_dims[i], 0, 0};
     gb += h_emb_floats[i];
   }
   return 0;
@@ -394,32 +438,42 @@ struct DevPlan {
 
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// One host image of every small array a launch needs, uploaded with ONE copy (seven separate
+// copies of a few hundred bytes cost ~140 us of stream time in front of the gradient's first
+// kernel). `more`: further (pointer, bytes) pieces, returned in dp->more in the same order.
+struct Piece { const void* ptr; size_t bytes; };
 static int upload_plan(const HostPlan& hp, const void* const* h_outs, int n_outs, size_t extra,
-                       DevPlan* dp, hipStream_t st) {
-  const size_t b_sl = al256(hp.slices.size() * sizeof(SliceDev) + 1);
-  const size_t b_gr = al256(hp.groups.size() * sizeof(GroupDev) + 1);
-  const size_t b_bf = al256(hp.bufs.size() * sizeof(BufDev) + 1);
-  const size_t b_ou = al256((size_t)n_outs * sizeof(void*) + 1);
-  MONO_TRY(g_lws.ensure(b_sl + b_gr + b_bf + b_ou + extra + 256));
+                       DevPlan* dp, hipStream_t st, const std::vector<Piece>& more = {},
+                       std::vector<char*>* more_dev = nullptr) {
+  std::vector<Piece> pieces = {
+      {hp.slices.data(), hp.slices.size() * sizeof(SliceDev)},
+      {hp.groups.data(), hp.groups.size() * sizeof(GroupDev)},
+      {hp.bufs.data(), hp.bufs.size() * sizeof(BufDev)},
+      {h_outs, (size_t)n_outs * sizeof(void*)}};
+  pieces.insert(pieces.end(), more.begin(), more.end());
+  std::vector<size_t> off(pieces.size());
+  size_t total = 0;
+  for (size_t i = 0; i < pieces.size(); ++i) {
+    off[i] = total;
+    total += al256(pieces[i].bytes + 1);
+  }
+  MONO_TRY(g_lws.ensure(total + extra + 256));
+  static std::vector<char> image;  // (one host thread per GPU)
+  image.assign(total, 0);
+  for (size_t i = 0; i < pieces.size(); ++i)
+    if (pieces[i].bytes) memcpy(image.data() + off[i], pieces[i].ptr, pieces[i].bytes);
   char* p = (char*)g_lws.ptr;
-  dp->slices = (SliceDev*)p; p += b_sl;
-  dp->groups = (GroupDev*)p; p += b_gr;
-  dp->bufs = (BufDev*)p; p += b_bf;
-  dp->outs = (float**)p; p += b_ou;
-  dp->rest = p;
-  // pageable sources: hipMemcpyAsync stages them before returning, so the vectors may die
-  if (!hp.slices.empty())
-    MONO_HIP(hipMemcpyAsync(dp->slices, hp.slices.data(), hp.slices.size() * sizeof(SliceDev),
-                            hipMemcpyHostToDevice, st));
-  if (!hp.groups.empty())
-    MONO_HIP(hipMemcpyAsync(dp->groups, hp.groups.data(), hp.groups.size() * sizeof(GroupDev),
-                            hipMemcpyHostToDevice, st));
-  if (!hp.bufs.empty())
-    MONO_HIP(hipMemcpyAsync(dp->bufs, hp.bufs.data(), hp.bufs.size() * sizeof(BufDev),
-                            hipMemcpyHostToDevice, st));
-  if (n_outs > 0)
-    MONO_HIP(hipMemcpyAsync(dp->outs, h_outs, (size_t)n_outs * sizeof(void*), hipMemcpyHostToDevice,
-                            st));
+  // pageable source: hipMemcpyAsync stages it before returning, so `image` may be reused
+  if (total) MONO_HIP(hipMemcpyAsync(p, image.data(), total, hipMemcpyHostToDevice, st));
+  dp->slices = (SliceDev*)(p + off[0]);
+  dp->groups = (GroupDev*)(p + off[1]);
+  dp->bufs = (BufDev*)(p + off[2]);
+  dp->outs = (float**)(p + off[3]);
+  if (more_dev) {
+    more_dev->clear();
+    for (size_t i = 4; i < pieces.size(); ++i) more_dev->push_back(p + off[i]);
+  }
+  dp->rest = p + total;
   return 0;
 }
 
@@ -548,22 +602,43 @@ int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slice
   MONO_TRY(finish_plan(&hp, batch, "mono_embedding_to_layout_grad",
                        const_cast<float* const*>(h_out_grads)));
   long long total_floats = 0;
+  bool contiguous = true;  // the buffers follow each other in memory (views of one allocation)
   for (int i = 0; i < n_bufs; ++i) {
-    if (h_emb_floats[i] > 0)
-      MONO_HIP(hipMemsetAsync(h_emb_grads[i], 0, (size_t)h_emb_floats[i] * sizeof(float), st));
+    if (i + 1 < n_bufs) contiguous = contiguous && h_emb_grads[i + 1] == h_emb_grads[i] + h_emb_floats[i];
     total_floats += h_emb_floats[i];
+  }
+  if (contiguous && n_bufs > 0 && total_floats > 0) {
+    MONO_HIP(hipMemsetAsync(h_emb_grads[0], 0, (size_t)total_floats * sizeof(float), st));
+  } else {
+    for (int i = 0; i < n_bufs; ++i)
+      if (h_emb_floats[i] > 0)
+        MONO_HIP(hipMemsetAsync(h_emb_grads[i], 0, (size_t)h_emb_floats[i] * sizeof(float), st));
   }
   MONO_REQUIRE(total_floats < (long long)0xFFFFFFF0ll,
                "mono_embedding_to_layout_grad: gradient buffers exceed 2^32 floats");
   if (n_slices == 0 || batch == 0 || n_fids == 0) return 0;
-  // contribution ranges need feature_offset on the host
-  std::vector<int32_t> fo((size_t)n_features);
-  MONO_HIP(hipMemcpyAsync(fo.data(), feature_offset, (size_t)n_features * sizeof(int32_t),
-                          hipMemcpyDeviceToHost, st));
+  // contribution ranges: two feature_offset entries per slice (start of its first run, end of its
+  // last), picked on the device and read back in one small copy
+  std::vector<int32_t> pick_idx((size_t)2 * n_slices, -1), pick((size_t)2 * n_slices, 0);
+  for (int i = 0; i < n_slices; ++i) {
+    const SliceDev& s = hp.slices[i];
+    if (!s.feature_num) continue;
+    pick_idx[2 * i] = s.f0;
+    const long long e = s.shared ? (long long)s.f0 + 1 : (long long)s.f0 + batch;  // run_end(e - 1)
+    pick_idx[2 * i + 1] = e < n_features ? (int32_t)e : -1;
+  }
+  static Workspace pick_ws;
+  MONO_TRY(pick_ws.ensure((size_t)4 * n_slices * sizeof(int32_t) + 256));
+  int32_t* d_pick_idx = (int32_t*)pick_ws.ptr;
+  int32_t* d_pick = d_pick_idx + 2 * n_slices;
+  MONO_HIP(hipMemcpyAsync(d_pick_idx, pick_idx.data(), pick_idx.size() * sizeof(int32_t),
+                          hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_pick_i32, dim3((2 * n_slices + 255) / 256), dim3(256), 0, st, feature_offset,
+                     d_pick_idx, 2 * n_slices, (int32_t)n_fids, d_pick);
+  MONO_HIP(hipGetLastError());
+  MONO_HIP(hipMemcpyAsync(pick.data(), d_pick, pick.size() * sizeof(int32_t), hipMemcpyDeviceToHost,
+                          st));
   MONO_HIP(hipStreamSynchronize(st));
-  auto run_end = [&](int f) -> long long {  // one past the last fid position of feature run f
-    return f < n_features - 1 ? fo[f + 1] : n_fids;
-  };
   std::vector<GradSliceDev> gs(n_slices);
   long long nc = 0;
   for (int i = 0; i < n_slices; ++i) {
@@ -572,39 +647,73 @@ int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slice
     gs[i].p0 = 0;
     gs[i].len0 = 1;
     if (!s.feature_num) continue;
-    gs[i].p0 = fo[s.f0];
+    gs[i].p0 = pick[2 * i];
+    const long long len = (long long)pick[2 * i + 1] - pick[2 * i];
+    MONO_REQUIRE(len >= 0, "mono_embedding_to_layout_grad: feature_offset is not ascending");
     if (s.shared) {
-      gs[i].len0 = (int)(run_end(s.f0) - fo[s.f0]);
+      gs[i].len0 = (int)len;
       nc += (long long)batch * gs[i].len0;
       if (gs[i].len0 == 0) gs[i].len0 = 1;
     } else {
-      nc += run_end(s.f0 + batch - 1) - fo[s.f0];
+      nc += len;
     }
   }
   if (nc == 0) return 0;
   MONO_REQUIRE(nc < (long long)0xFFFFFFF0ll, "mono_embedding_to_layout_grad: too many uses");
+  // keys count units of key_unit floats: every destination offset is gbase + row * dim + start
+  auto gcd = [](long long x, long long y) {
+    while (y) { const long long r = x % y; x = y; y = r; }
+    return x;
+  };
+  long long unit = 0;
+  for (const BufDev& bd : hp.bufs)
+    if (bd.floats > 0) unit = gcd(unit, bd.dim);
+  for (const SliceDev& sl : hp.slices) unit = gcd(unit, sl.start);
+  if (unit <= 0) unit = 1;
+  // packed source descriptors when slice | sample | seq fit one 32-bit value
+  auto nbits = [](long long v) { return v <= 0 ? 0 : bits_for_l((uint64_t)v); };
+  const int sbits = nbits(n_slices - 1), bbits = nbits(batch - 1);
+  int qbits = 0;
+  for (const SliceDev& sl : hp.slices)
+    if (sl.pooling == MONO_POOL_FIRSTN) qbits = std::max(qbits, nbits(sl.max_seq - 1));
+  static const bool force_ptrs = getenv("MONO_LAYOUT_GRAD_PTRS") != nullptr;  // test switch
+  const bool packed = sbits + bbits + qbits <= 32 && !force_ptrs;
   const size_t n_al = ((size_t)nc + 63) & ~(size_t)63;
-  const size_t b_gs = al256((size_t)n_slices * sizeof(GradSliceDev));
-  const size_t b_dims = al256((size_t)n_slices * sizeof(int32_t));
-  const size_t extra = b_gs + b_dims + 4 * n_al * sizeof(uint32_t) + n_al * sizeof(void*) + 1024;
-  DevPlan dp;
-  MONO_TRY(upload_plan(hp, (const void* const*)h_out_grads, n_outs, extra, &dp, st));
-  char* p = dp.rest;
-  GradSliceDev* d_gs = (GradSliceDev*)p; p += b_gs;
-  int32_t* d_dims = (int32_t*)p; p += b_dims;
-  {
-    std::vector<int32_t> h_dims(n_slices);
-    for (int i = 0; i < n_slices; ++i) h_dims[i] = hp.slices[i].dim;
-    MONO_HIP(hipMemcpyAsync(d_dims, h_dims.data(), (size_t)n_slices * sizeof(int32_t),
-                            hipMemcpyHostToDevice, st));
+  const size_t extra = 5 * n_al * sizeof(uint32_t) +
+                       (packed ? 0 : n_al * sizeof(void*)) + 1024;
+  std::vector<int32_t> h_dims(n_slices);
+  std::vector<SrcTab> h_tab(n_slices);
+  for (int i = 0; i < n_slices; ++i) {
+    const SliceDev& sl = hp.slices[i];
+    h_dims[i] = sl.dim;
+    h_tab[i].base = h_out_grads[sl.out_index] + sl.out_offset;
+    h_tab[i].stride = sl.out_stride;
+    h_tab[i].seq_stride = sl.pooling == MONO_POOL_FIRSTN ? sl.dim : 0;
   }
-  const float** srcp = (const float**)p; p += al256(n_al * sizeof(void*));
+  // destinations in key units (no division on the device)
+  for (BufDev& bd : hp.bufs) {
+    bd.gbase_u = bd.gbase / unit;
+    bd.dim_u = (int)(bd.dim / unit);
+  }
+  for (int i = 0; i < n_slices; ++i) gs[i].start_u = (int)(hp.slices[i].start / unit);
+  DevPlan dp;
+  std::vector<char*> more_dev;
+  MONO_TRY(upload_plan(hp, (const void* const*)h_out_grads, n_outs, extra, &dp, st,
+                       {{gs.data(), (size_t)n_slices * sizeof(GradSliceDev)},
+                        {h_dims.data(), (size_t)n_slices * sizeof(int32_t)},
+                        {h_tab.data(), (size_t)n_slices * sizeof(SrcTab)}},
+                       &more_dev));
+  GradSliceDev* d_gs = (GradSliceDev*)more_dev[0];
+  int32_t* d_dims = (int32_t*)more_dev[1];
+  SrcTab* d_tab = (SrcTab*)more_dev[2];
+  char* p = dp.rest;
+  const float** srcp = nullptr;
+  if (!packed) { srcp = (const float**)p; p += al256(n_al * sizeof(void*)); }
   uint32_t* key = (uint32_t*)p; p += n_al * sizeof(uint32_t);
-  uint32_t* cslice = (uint32_t*)p; p += n_al * sizeof(uint32_t);
+  uint32_t* val = (uint32_t*)p; p += n_al * sizeof(uint32_t);   // packed values / slices
   uint32_t* skey = (uint32_t*)p; p += n_al * sizeof(uint32_t);
-  uint32_t* sidx = (uint32_t*)p;
-  MONO_HIP(hipMemcpyAsync(d_gs, gs.data(), (size_t)n_slices * sizeof(GradSliceDev),
-                          hipMemcpyHostToDevice, st));
+  uint32_t* sval = (uint32_t*)p;
+  const long long n_units = (total_floats + unit - 1) / unit;
   GradArgs a{};
   a.l.slices = dp.slices; a.l.groups = dp.groups; a.l.bufs = dp.bufs; a.l.outs = nullptr;
   a.l.n_slices = n_slices; a.l.n_groups = (int)hp.groups.size(); a.l.n_bufs = n_bufs;
@@ -614,36 +723,51 @@ int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slice
   a.gs = d_gs;
   a.out_grads = (const float* const*)dp.outs;
   a.n_contrib = nc;
-  a.key = key; a.cslice = cslice; a.srcp = srcp;
-  a.nokey = (uint32_t)total_floats;
+  a.key = key; a.val = val; a.cslice = val; a.srcp = srcp;
+  a.nokey = (uint32_t)n_units;
+  a.key_unit = (int)unit;
+  a.packed = packed ? 1 : 0; a.sbits = sbits; a.bbits = bbits;
   hipLaunchKernelGGL(k_layout_grad_enumerate, dim3(grid_for(nc, 256)), dim3(256), 0, st, a);
   MONO_HIP(hipGetLastError());
-  const int end_bit = bits_for_l((uint64_t)total_floats);  // nokey = total_floats sorts last
+  const int end_bit = bits_for_l((uint64_t)n_units);  // nokey = n_units sorts last
   const size_t tmp = sort_pairs_tmp_bytes((size_t)nc, end_bit);
   MONO_TRY(g_lws_sort.ensure(tmp));
-  MONO_TRY(sort_pairs_u32(key, skey, nullptr, sidx, (size_t)nc, end_bit, g_lws_sort.ptr, tmp, st));
+  // packed: the sort carries the descriptors; pointer form: the contribution indices
+  MONO_TRY(sort_pairs_u32(key, skey, packed ? val : nullptr, sval, (size_t)nc, end_bit,
+                          g_lws_sort.ptr, tmp, st));
   // Every destination's uses are now one run of the sorted keys, in the reference's order: summed
   // by the table's segment machinery (sub-group walk, long-segment kernel, chunk combine), one
   // pass per distinct slice width. (One sub-group walking a run on its own took 64 ms for a
   // config-3 batch: a Zipf head is hundreds of thousands of uses of one FID.) The result is built
-  // in one contiguous scratch image of all buffers and copied out.
+  // in one contiguous image of all buffers: the caller's own memory when its buffers follow each
+  // other (views of one allocation, the V2 sub-ranges of one tensor), else a scratch copied out.
   static Workspace grad_img;
-  MONO_TRY(grad_img.ensure((size_t)total_floats * sizeof(float) + 256));
-  float* img = (float*)grad_img.ptr;
-  MONO_HIP(hipMemsetAsync(img, 0, (size_t)total_floats * sizeof(float), st));
+  float* img = n_bufs > 0 ? h_emb_grads[0] : nullptr;
+  if (!contiguous) {
+    MONO_TRY(grad_img.ensure((size_t)total_floats * sizeof(float) + 256));
+    img = (float*)grad_img.ptr;
+    MONO_HIP(hipMemsetAsync(img, 0, (size_t)total_floats * sizeof(float), st));
+  }
   std::vector<int> widths;
   for (int i = 0; i < n_slices; ++i)
     if (std::find(widths.begin(), widths.end(), hp.slices[i].dim) == widths.end())
       widths.push_back(hp.slices[i].dim);
-  for (int w : widths)
-    MONO_TRY(segment_set_sum_rows(skey, sidx, nc, srcp, cslice, d_dims, w, hp.vec == 4,
-                                  (uint32_t)total_floats, img, st));
-  long long gb = 0;
-  for (int i = 0; i < n_bufs; ++i) {
-    if (h_emb_floats[i] > 0)
-      MONO_HIP(hipMemcpyAsync(h_emb_grads[i], img + gb, (size_t)h_emb_floats[i] * sizeof(float),
-                              hipMemcpyDeviceToDevice, st));
-    gb += h_emb_floats[i];
+  for (int w : widths) {
+    if (packed)
+      MONO_TRY(segment_set_sum_packed(skey, sval, nc, d_tab, sbits, bbits, d_dims, w, (int)unit,
+                                      hp.vec == 4, (uint32_t)n_units, img, st));
+    else
+      MONO_TRY(segment_set_sum_rows(skey, sval, nc, srcp, val, d_dims, w, hp.vec == 4,
+                                    (uint32_t)n_units, img, st, (int)unit));
+  }
+  if (!contiguous) {
+    long long gb = 0;
+    for (int i = 0; i < n_bufs; ++i) {
+      if (h_emb_floats[i] > 0)
+        MONO_HIP(hipMemcpyAsync(h_emb_grads[i], img + gb, (size_t)h_emb_floats[i] * sizeof(float),
+                                hipMemcpyDeviceToDevice, st));
+      gb += h_emb_floats[i];
+    }
   }
   return 0;
 }

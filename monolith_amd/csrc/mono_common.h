@@ -99,7 +99,20 @@ int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, con
 // (cls[occurrence] -> cls_dim[class]); keys equal to skip_key are ignored.
 int segment_set_sum_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n,
                          const float* const* src_ptrs, const uint32_t* cls, const int32_t* cls_dim,
-                         int D, bool aligned4, uint32_t skip_key, float* out, hipStream_t st);
+                         int D, bool aligned4, uint32_t skip_key, float* out, hipStream_t st,
+                         int key_unit = 1);
+// The same sum with the source row of an occurrence packed into its 32-bit value instead of looked
+// up through a pointer array: value = class | sample << sbits | seq << (sbits + bbits), source row =
+// tab[class].base + sample * tab[class].stride + seq * tab[class].seq_stride (one dependent memory
+// level and 12 bytes per occurrence less than segment_set_sum_rows). Keys count units of
+// `key_unit` floats: out[key * key_unit .. + D).
+struct SrcTab {
+  const float* base;
+  int32_t stride, seq_stride;
+};
+int segment_set_sum_packed(const uint32_t* skeys, const uint32_t* svals, int64_t n, const SrcTab* tab,
+                           int sbits, int bbits, const int32_t* cls_dim, int D, int key_unit,
+                           bool aligned4, uint32_t skip_key, float* out, hipStream_t st);
 // host-side call timing, printed at exit when MONO_HOST_PROF is set (table.hip)
 bool host_prof_on();
 double host_now();

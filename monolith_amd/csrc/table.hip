@@ -695,12 +695,24 @@ struct ApplyArgs {
   const int32_t* cls_dim;
   int want_dim;      // 0 = every segment
   uint32_t skip_slot;  // sorted key that marks "no destination" (besides kNoSlot)
+  // packed sources (segment_set_sum_packed): occurrence value = class | sample << pk_sbits |
+  // seq << pk_qshift; its row = src_tab[class].base + sample * stride + seq * seq_stride, its class
+  // (k_classify's width filter) = value & pk_smask
+  const SrcTab* src_tab;
+  uint32_t pk_smask, pk_bmask;
+  int pk_sbits, pk_qshift;
+  int64_t max_heads;  // the caller's bound on the number of distinct keys (0: n), sizes k_apply's grid
 };
 // PTRS: can this instantiation be given per-occurrence source pointers at all? (Only the set-sum
 // mode is; a run-time test in every other kernel's gradient loads cost the headline k_apply a
 // quarter of its speed.)
 template <bool PTRS>
 __device__ __forceinline__ const float* src_row(const ApplyArgs& a, uint32_t idx, int D) {
+  if (PTRS && a.src_tab) {
+    const SrcTab s = a.src_tab[idx & a.pk_smask];
+    return s.base + (int64_t)((idx >> a.pk_sbits) & a.pk_bmask) * s.stride +
+           (int64_t)(idx >> a.pk_qshift) * s.seq_stride;
+  }
   if (PTRS && a.src_ptrs) return a.src_ptrs[idx];
   return a.src + (uint64_t)idx * D;
 }
@@ -906,17 +918,22 @@ __device__ __forceinline__ void optx_store(const SegDev& sg, float* row, int e, 
   }
 }
 
-__device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t end, int64_t key,
-                                    uint32_t slot, uint32_t fresh) {
+__device__ __forceinline__ bool long_split(const ApplyArgs& a, int64_t len) {
+  return a.mode != MODE_OPT_SEQ && len > a.chunk;
+}
+__device__ __forceinline__ uint32_t long_parts(const ApplyArgs& a, int64_t len) {
+  return long_split(a, len) ? (uint32_t)((len + a.chunk - 1) / a.chunk) : 1u;
+}
+// queue entries q .. q + nparts; a split key also takes partial rows pbase .. + nparts and the
+// split-key entry c (all three reserved by the caller)
+__device__ inline void enqueue_long_at(const ApplyArgs& a, int64_t first, int64_t end, int64_t key,
+                                       uint32_t slot, uint32_t fresh, uint32_t q, uint32_t pbase,
+                                       uint32_t c) {
   const int64_t len = end - first;
-  const bool split = a.mode != MODE_OPT_SEQ && len > a.chunk;
-  const uint32_t nparts = split ? (uint32_t)((len + a.chunk - 1) / a.chunk) : 1u;
+  const bool split = long_split(a, len);
+  const uint32_t nparts = long_parts(a, len);
   const int64_t csz = (len + nparts - 1) / nparts;
-  const uint32_t q = atomicAdd(&a.qcount[0], nparts);
-  uint32_t pbase = kNoPart;
   if (split) {
-    pbase = atomicAdd(&a.qcount[3], nparts);
-    const uint32_t c = atomicAdd(&a.qcount[2], 1u);
     SplitSeg sp;
     sp.key = key; sp.slot = slot; sp.fresh = fresh; sp.pbase = pbase; sp.nparts = nparts;
     a.cqueue[c] = sp;
@@ -930,6 +947,19 @@ __device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t e
     ls.pad = 0;
     a.queue[q + p] = ls;
   }
+}
+__device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t end, int64_t key,
+                                    uint32_t slot, uint32_t fresh) {
+  const int64_t len = end - first;
+  const bool split = long_split(a, len);
+  const uint32_t nparts = long_parts(a, len);
+  const uint32_t q = atomicAdd(&a.qcount[0], nparts);
+  uint32_t pbase = kNoPart, c = 0;
+  if (split) {
+    pbase = atomicAdd(&a.qcount[3], nparts);
+    c = atomicAdd(&a.qcount[2], 1u);
+  }
+  enqueue_long_at(a, first, end, key, slot, fresh, q, pbase, c);
 }
 
 // Write path, step 2: one 8-lane sub-group per distinct key walks that key's occurrences in
@@ -1238,17 +1268,20 @@ constexpr int kClsThreads = 1024;
 constexpr int kClsItems = 4;
 __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow_long,
                                                           uint4* __restrict__ heads) {
-  __shared__ uint32_t s_cnt, s_base;
+  __shared__ uint32_t s_cnt, s_base, s_lq, s_lp, s_lc, s_lqb, s_lpb, s_lcb;
   const uint32_t* __restrict__ sk = static_cast<const uint32_t*>(a.skeys);
   const int64_t n = a.n;
   const int tid = threadIdx.x, lane = tid & 63;
   // a sort that failed (look-back time-out) leaves stale ping-pong data behind: emit no heads and
   // no long segments, so that nothing is applied; the host reports the word at its next read-back
   if (a.sort_err && *a.sort_err != 0u) return;
-  if (tid == 0) s_cnt = 0;
+  if (tid == 0) s_cnt = s_lq = s_lp = s_lc = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * (kClsThreads * kClsItems);
   uint32_t loc[kClsItems], len[kClsItems], slotv[kClsItems], idxv[kClsItems];
+  // long segments: queue entries / partial rows / split-key entries reserved in LDS first, one
+  // global atomic per counter and workgroup (a Zipf-heavy batch queues thousands of them)
+  uint32_t lq[kClsItems], lp[kClsItems], lc[kClsItems];
   bool sh[kClsItems];
 #pragma unroll
   for (int k = 0; k < kClsItems; ++k) {
@@ -1256,6 +1289,8 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
     sh[k] = false;
     len[k] = 1;
     loc[k] = 0;
+    lq[k] = kNoPart;
+    lp[k] = lc[k] = 0;
     slotv[k] = idxv[k] = 0;
     if (j < n) {
       const uint32_t slot = sk[j];
@@ -1264,13 +1299,20 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
       const uint32_t prev = j > 0 ? sk[j - 1] : ~slot;
       const uint32_t next = j + 1 < n ? sk[j + 1] : ~slot;
       bool keep = prev != slot && slot != kNoSlot && slot != a.skip_slot;
-      if (keep && a.want_dim) keep = a.cls_dim[a.cls[idxv[k]]] == a.want_dim;
+      if (keep && a.want_dim)
+        keep = a.cls_dim[a.src_tab ? (idxv[k] & a.pk_smask) : a.cls[idxv[k]]] == a.want_dim;
       if (keep) {
         if (next == slot) len[k] = (uint32_t)(segment_end<uint32_t>(sk, j, n, slot) - j);
-        if (allow_long && len[k] > (uint32_t)kLongSeg)
-          enqueue_long(a, j, j + len[k], 0, slot, 0u);
-        else
+        if (allow_long && len[k] > (uint32_t)kLongSeg) {
+          const uint32_t nparts = long_parts(a, len[k]);
+          lq[k] = atomicAdd(&s_lq, nparts);
+          if (long_split(a, len[k])) {
+            lp[k] = atomicAdd(&s_lp, nparts);
+            lc[k] = atomicAdd(&s_lc, 1u);
+          }
+        } else {
           sh[k] = true;
+        }
       }
     }
     const unsigned long long m = __ballot(sh[k]);
@@ -1284,13 +1326,18 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
   }
   __syncthreads();
   if (tid == 0) s_base = s_cnt ? atomicAdd(&a.qcount[1], s_cnt) : 0u;
+  if (tid == 64) s_lqb = s_lq ? atomicAdd(&a.qcount[0], s_lq) : 0u;
+  if (tid == 128) s_lpb = s_lp ? atomicAdd(&a.qcount[3], s_lp) : 0u;
+  if (tid == 192) s_lcb = s_lc ? atomicAdd(&a.qcount[2], s_lc) : 0u;
   __syncthreads();
   const uint32_t gb = s_base;
 #pragma unroll
-  for (int k = 0; k < kClsItems; ++k)
-    if (sh[k])
-      heads[gb + loc[k]] = make_uint4((uint32_t)(base + (int64_t)k * kClsThreads + tid), len[k],
-                                      slotv[k], idxv[k]);
+  for (int k = 0; k < kClsItems; ++k) {
+    const int64_t j = base + (int64_t)k * kClsThreads + tid;
+    if (sh[k]) heads[gb + loc[k]] = make_uint4((uint32_t)j, len[k], slotv[k], idxv[k]);
+    if (lq[k] != kNoPart)
+      enqueue_long_at(a, j, j + len[k], 0, slotv[k], 0u, s_lqb + lq[k], s_lpb + lp[k], s_lcb + lc[k]);
+  }
 }
 
 // Long segments: one 256-thread workgroup per key (or per chunk of a split key), split into
@@ -1308,7 +1355,11 @@ constexpr int kLMaxRows = 2 * kLoaders;        // rows per tile (two prefetched 
 constexpr int kLIdxRing = 8;
 
 template <int OPTK, int MODE>
-__global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
+// (two workgroups per CU for the stateless sum of the layout gradient — it runs hundreds of
+// thousands of rows through these chains and nothing else competes for the CUs' registers; beside
+// the table's k_apply the second workgroup costs the sub-group kernel more than it gains:
+// config 2 355 -> 396 us per step)
+__global__ void __launch_bounds__(256, MODE == MODE_SET_SUM ? 2 : 1) k_apply_long(TableDev t, ApplyArgs a) {
   __shared__ __attribute__((aligned(16))) float tile[2][kLTileFloats];
   __shared__ uint32_t idxs[kLIdxRing][kLMaxRows];
   __shared__ uint32_t s_qi;
@@ -1316,7 +1367,7 @@ __global__ void __launch_bounds__(256) k_apply_long(TableDev t, ApplyArgs a) {
   const int tid = threadIdx.x;
   const bool loader = tid >= 64;
   const int lt = tid - 64;  // loader thread index
-  const bool vec4 = (D & 3) == 0 && (a.src_ptrs ? a.src_aligned4 != 0
+  const bool vec4 = (D & 3) == 0 && ((a.src_ptrs || a.src_tab) ? a.src_aligned4 != 0
                                                 : (reinterpret_cast<uintptr_t>(a.src) & 15) == 0);
   constexpr bool kSums = MODE == MODE_OPT_DEDUP || MODE == MODE_SET_SUM;
   const uint32_t nq = *a.qcount;
@@ -1779,7 +1830,11 @@ static void launch_lookup(const Table* t, const int64_t* ids, int64_t n, float* 
 
 template <int V, int OPTK>
 static void launch_apply_vo(const Table* t, const ApplyArgs& a, hipStream_t st) {
-  const dim3 grid((unsigned)((a.n + 31) / 32));
+  // (with compacted heads a sub-group beyond *nheads has nothing to do: when the caller knows a
+  // bound on the distinct keys — the layout gradient's 1.4 M rows for 6.5 M uses — four fifths of
+  // the workgroups need not be dispatched at all)
+  const int64_t work = a.heads && a.max_heads > 0 ? std::min(a.n, a.max_heads) : a.n;
+  const dim3 grid((unsigned)((work + 31) / 32));
   // no-filter path (slots resolved, heads compacted): the walking modes as instantiations of
   // their own; everything else (filter path, assign, import) through the run-time kernel
   if (!a.from_keys && a.heads && a.mode == MODE_OPT_DEDUP)
@@ -2460,7 +2515,8 @@ int segment_add_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n, con
 // Keys equal to skip_key name no destination. Same machinery as segment_add_rows.
 int segment_set_sum_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n,
                          const float* const* src_ptrs, const uint32_t* cls, const int32_t* cls_dim,
-                         int D, bool aligned4, uint32_t skip_key, float* out, hipStream_t st) {
+                         int D, bool aligned4, uint32_t skip_key, float* out, hipStream_t st,
+                         int key_unit) {
   static Table ctx;
   if (n == 0) return 0;
   MONO_REQUIRE(D > 0 && D <= kTileFloats, "segment_set_sum_rows: dim %d exceeds %d", D, kTileFloats);
@@ -2468,7 +2524,7 @@ int segment_set_sum_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n,
   t->d = TableDev{};
   t->d.rows = out;
   t->d.dim = D;
-  t->d.row_floats = 1;
+  t->d.row_floats = key_unit;
   t->d.n_seg = 1;
   t->d.seg[0].dim = D;
   t->d.seg[0].opt_kind = MONO_OPT_SGD;
@@ -2486,6 +2542,50 @@ int segment_set_sum_rows(const uint32_t* skeys, const uint32_t* sidx, int64_t n,
   a.cls_dim = cls_dim;
   a.want_dim = D;
   a.skip_slot = skip_key;
+  a.mode = MODE_SET_SUM;
+  a.sort_err = sort_error_word();
+  MONO_TRY(t->ws.ensure(queue_bytes(n, D)));
+  uint4* heads = nullptr;
+  MONO_TRY(queue_setup(&a, (char*)t->ws.ptr, n, D, &heads, st));
+  MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st));
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+int segment_set_sum_packed(const uint32_t* skeys, const uint32_t* svals, int64_t n, const SrcTab* tab,
+                           int sbits, int bbits, const int32_t* cls_dim, int D, int key_unit,
+                           bool aligned4, uint32_t skip_key, float* out, hipStream_t st) {
+  static Table ctx;
+  if (n == 0) return 0;
+  MONO_REQUIRE(D > 0 && D <= kTileFloats, "segment_set_sum_packed: dim %d exceeds %d", D, kTileFloats);
+  MONO_REQUIRE(tab && key_unit >= 1 && sbits >= 0 && bbits >= 0 && sbits + bbits <= 32,
+               "segment_set_sum_packed: bad packing");
+  Table* t = &ctx;
+  t->d = TableDev{};
+  t->d.rows = out;
+  t->d.dim = D;
+  t->d.row_floats = key_unit;
+  t->d.n_seg = 1;
+  t->d.seg[0].dim = D;
+  t->d.seg[0].opt_kind = MONO_OPT_SGD;
+  t->d.seg[0].st_off = D;
+  t->opt_tmpl = OPTK_SGD;
+  t->vec = 1;
+  if (aligned4) t->vec = D % 32 == 0 ? 4 : D % 16 == 0 ? 2 : 1;
+  ApplyArgs a{};
+  a.skeys = skeys;
+  a.sidx = svals;
+  a.n = n;
+  a.src_tab = tab;
+  a.pk_sbits = sbits;
+  a.pk_smask = sbits >= 32 ? 0xFFFFFFFFu : ((1u << sbits) - 1u);
+  a.pk_bmask = bbits >= 32 ? 0xFFFFFFFFu : ((1u << bbits) - 1u);
+  a.pk_qshift = std::min(sbits + bbits, 31);  // (no seq bits: every seq_stride is 0)
+  a.src_aligned4 = aligned4 ? 1 : 0;
+  a.cls_dim = cls_dim;
+  a.want_dim = D;
+  a.skip_slot = skip_key;
+  a.max_heads = (int64_t)skip_key;  // keys are < skip_key
   a.mode = MODE_SET_SUM;
   a.sort_err = sort_error_word();
   MONO_TRY(t->ws.ensure(queue_bytes(n, D)));

@@ -390,7 +390,13 @@ def fused_embedding_to_layout_grad(nfl_offset, feature_offset, fid_offset, batch
   plan = fc.build_layout_plan(feature_cfgs)
   dev = _dev(fid_offset, "fused_embedding_to_layout_grad")
   bufs = _layout_buffers(plan, embeddings_list, fid_list_row_split, ps_num, version)
-  grads = [torch.zeros_like(e, dtype=torch.float32).contiguous() for e in embeddings_list]
+  # one allocation, one view per tensor: the library zero-fills and sums straight into it (its
+  # buffers then follow each other in memory; separate tensors cost a scratch image and a copy)
+  flat = torch.empty(sum(int(e.numel()) for e in embeddings_list), dtype=torch.float32, device=dev)
+  grads, at = [], 0
+  for e in embeddings_list:
+    grads.append(flat[at:at + e.numel()].view(e.shape))
+    at += int(e.numel())
   gouts = [g.to(torch.float32).contiguous() for g in layout_tensors_grad]
   _layout_call(plan, bufs, grads, fid_offset.contiguous(),
                feature_offset.to(torch.int32).contiguous(), nfl_offset, _batch(batch_size), gouts,

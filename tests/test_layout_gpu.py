@@ -134,3 +134,20 @@ def test_fused_lookup_to_layout_equals_lookup_then_layout(dim, opt, batch, ps_nu
   for i, (a, b, e) in enumerate(zip(fused, two_step, exp)):
     assert np.array_equal(a.cpu().numpy().view(np.uint32), b.detach().cpu().numpy().view(np.uint32)), i
     assert np.array_equal(a.cpu().numpy().view(np.uint32), e.view(np.uint32)), i
+
+
+def test_layout_gradient_pointer_form_subprocess():
+  """The gradient's fallback for (slice, sample, seq) descriptors that do not fit 32 bits — per-use
+  source pointers — is the same code path MONO_LAYOUT_GRAD_PTRS=1 forces; the switch is read once
+  per process, so the bit-exact layout cases run again in a child process with it set."""
+  import os
+  import subprocess
+  import sys
+  env = dict(os.environ, MONO_LAYOUT_GRAD_PTRS="1")
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
+                      os.path.join(root, "tests", "test_layout_gpu.py"), "-k",
+                      "test_layout_forward_and_gradient_bit_exact", "--timeout", "120",
+                      "--timeout-method", "thread"], env=env, cwd=root, capture_output=True,
+                     text=True, timeout=600)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
