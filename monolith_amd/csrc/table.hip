@@ -1494,12 +1494,32 @@ __global__ void __launch_bounds__(256, MODE == MODE_SET_SUM ? 2 : 1) k_apply_lon
           have_acc = true;
           r = 1;
         }
-        for (; r + 8 <= rows; r += 8) {  // eight LDS reads in flight, the adds stay in order
-          float v[8];
+        // eight LDS reads in flight and the NEXT eight issued before this eight's dependent adds
+        // (two register sets, alternating): the chain then waits on its adds, not on LDS
+        if (r + 8 <= rows) {
+          float va[8], vb[8];
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = tp[(r + k) * Dw];
+          for (int k = 0; k < 8; ++k) va[k] = tp[(r + k) * Dw];
+          for (;;) {
+            const bool more_b = r + 16 <= rows;
+            if (more_b) {
 #pragma unroll
-          for (int k = 0; k < 8; ++k) step(v[k]);
+              for (int k = 0; k < 8; ++k) vb[k] = tp[(r + 8 + k) * Dw];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) step(va[k]);
+            r += 8;
+            if (!more_b) break;
+            const bool more_a = r + 16 <= rows;
+            if (more_a) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) va[k] = tp[(r + 8 + k) * Dw];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) step(vb[k]);
+            r += 8;
+            if (!more_a) break;
+          }
         }
         for (; r < rows; ++r) step(tp[r * Dw]);
       };

@@ -80,7 +80,16 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
 
   def __init__(self, shard_num: int,
                table_factory: Callable[[int], multi_type_hash_table.BaseMultiTypeHashTable],
-               queue_configs: Optional[Dict[str, int]] = None, group=None, ops=None):
+               queue_configs: Optional[Dict[str, int]] = None, group=None, ops=None,
+               grad_exchange_bits: Optional[int] = None):
+    # grad_exchange_bits: 32 (default) or 16 = the gradient rows cross the fabric as binary16
+    # (distributed_ps_sync.py:353-356,381-385: tf.cast(grad_flat, tf.float16) before the exchange,
+    # back to float32 behind it). Default from MONOLITH_WITH_BYTEPS_BWD_CAST, the reference's
+    # own switch (:44-47).
+    if grad_exchange_bits is None:
+      grad_exchange_bits = int(os.environ.get("MONOLITH_WITH_BYTEPS_BWD_CAST", "32"))
+    assert grad_exchange_bits in (16, 32), "grad_exchange_bits must be 16 or 32"
+    self._grad_bits = grad_exchange_bits
     self._shard_num = shard_num
     self._group = group
     rank, world = _world(group)
@@ -197,8 +206,12 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
 
     recv_emb_splits = auxiliary_bundle.pop("recv_emb_splits")
     embedding_splits = auxiliary_bundle.pop("embedding_splits")
+    if self._grad_bits == 16:  # to nearest even, as tf.cast; overflow -> inf, like the reference
+      grad_flat = grad_flat.to(torch.float16)
     grad_flat_t, _ = alltoall(grad_flat, recv_emb_splits.tolist(),
                               recv_splits=embedding_splits.tolist(), group=self._group)
+    if self._grad_bits == 16:
+      grad_flat_t = grad_flat_t.to(torch.float32)
     auxiliary_bundle.pop("shard_sizes")
     prefetched = None
     if next_slot_to_id is not None:

@@ -85,7 +85,14 @@ def _batch(rank, step):
   return ids, grads
 
 
-def _random(rank, world):
+def _random_fp16(rank, world):
+  """The same stream with the gradient rows exchanged as binary16 (the reference's
+  MONOLITH_WITH_BYTEPS_BWD_CAST=16, distributed_ps_sync.py:353-356): every per-rank in-order sum
+  is rounded to the nearest half (ties to even) before the owner applies it."""
+  _random(rank, world, grad_bits=16)
+
+
+def _random(rank, world, grad_bits=32):
   """Each rank draws its own batch (duplicates inside a rank and across ranks, an empty slot,
   negative ids -> signed floor-mod routing). Lookup results and the owner-side table state after
   each step equal a serial simulation: per owner shard, contributions applied source-rank-major,
@@ -96,7 +103,8 @@ def _random(rank, world):
   mk = lambda: {"a": cpu.seg(4, "adagrad"), "b": cpu.seg(2, "sgd"), "c": cpu.seg(3, "ftrl")}
   lrs = {"a": 0.1, "b": 0.5, "c": 0.01}
   table = distributed_ps_sync.DistributedMultiTypeHashTableMpi(world, _table_factory(mk(), lrs),
-                                                               ops=OracleOps)
+                                                               ops=OracleOps,
+                                                               grad_exchange_bits=grad_bits)
   # serial model of every owner shard (each rank simulates all of them)
   model = [{k: cpu.OracleTable([v]) for k, v in mk().items()} for _ in range(world)]
   for step in range(3):
@@ -128,6 +136,8 @@ def _random(rank, world):
             for row in g[v == u]:
               acc = acc + row
             summed[i] = acc
+          if grad_bits == 16:
+            summed = summed.astype(np.float16).astype(np.float32)
           model[n][k].apply_gradients(order, summed, [lrs[k]], req_time=100 + step,
                                       global_step=step)
     mine = table._table.tables
@@ -171,7 +181,8 @@ def _merged(rank, world):
   assert emb["slot1"].tolist() == [[-3.0 * world] * 2]
 
 
-@pytest.mark.parametrize("fn", [_basic, _random, _merged], ids=lambda f: f.__name__)
+@pytest.mark.parametrize("fn", [_basic, _random, _random_fp16, _merged],
+                         ids=lambda f: f.__name__)
 def test_world2_gloo(fn):
   _spawn(fn, 2)
 
