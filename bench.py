@@ -347,9 +347,11 @@ def main_config3(args, device):
 
   def p_grad():
     fid_list, fid_offset, feature_offset, nfl, batch, splits = st["sh"]
+    # (the gradient op reads only the SHAPE of the embedding list: with the fused forward there
+    # is no looked-up buffer, an unwritten tensor of that shape stands in)
+    emb = torch.empty((fid_list[0].numel() * D,), dtype=torch.float32, device=device)
     st["g"] = distribution_ops.fused_embedding_to_layout_grad(
-        nfl, feature_offset, fid_offset, batch, [st["emb"].reshape(-1)], splits, [gout],
-        "example_batch", cfgs, 1)
+        nfl, feature_offset, fid_offset, batch, [emb], splits, [gout], "example_batch", cfgs, 1)
 
   def p_apply(i):
     nonlocal table
@@ -357,15 +359,27 @@ def main_config3(args, device):
     table = table.apply_gradients(fid_list[0], st["g"][0].reshape(-1, D), global_step=i,
                                   req_time=10 + i)
 
+  two_step = not bool(getattr(args, "fused_forward", False))
+
   def step(i):
-    p_shard(i); p_lookup(); p_layout(); p_grad(); p_apply(i)
+    p_shard(i)
+    if two_step:
+      p_lookup(); p_layout()
+    else:
+      p_fused()
+    p_grad(); p_apply(i)
 
   dt = _timed_steps(step, args, torch.cuda.synchronize)
   u_per_step = float(np.mean([torch.cat([torch.unique(f.values) for f in b.values()]).numel()
                               for b in pool]))
-  ph = _phase_ms([("sharding_sparse_fids", lambda: p_shard(0)), ("lookup", p_lookup),
-                  ("layout_forward", p_layout), ("fused_lookup_to_layout", p_fused),
-                  ("layout_grad", p_grad), ("apply_gradients", lambda: p_apply(999))])
+  # phases in step order (the update then finds the slot record / prepared order of the step's
+  # own lookup); the forward the step does not use is timed on its own afterwards
+  fwd_two = [("lookup", p_lookup), ("layout_forward", p_layout)]
+  fwd_one = [("fused_lookup_to_layout", p_fused)]
+  ph = _phase_ms([("sharding_sparse_fids", lambda: p_shard(0))] + (fwd_two if two_step else fwd_one) +
+                 [("layout_grad", p_grad), ("apply_gradients", lambda: p_apply(999))])
+  ph.update(_phase_ms(fwd_one if two_step else fwd_two))
+  p_lookup(); p_layout(); p_fused()  # (no update in between: the same rows)
   same = all(torch.equal(a, b) for a, b in zip(st["out"], st["out2"]))
   # algorithmic bytes: pooled lookup per occurrence 8 (descriptor) + 4D (row read)
   # + 4D / L (pooled output); per unique FID the lookup moves 8 + 8 + 4D + 4D; the gradient
@@ -379,8 +393,9 @@ def main_config3(args, device):
       "layout_grad": n * (8 + 4 * D) + u * 4 * D,
       "apply_gradients": u * (8 + 4 * D) + u * (8 + 2 * 12 * D + 4),
   }
-  step_alg = sum(alg[k] for k in alg if k != "fused_lookup_to_layout")
-  dom = max((k for k in ph if k != "fused_lookup_to_layout"), key=lambda k: ph[k])
+  off_step = ("fused_lookup_to_layout",) if two_step else ("lookup", "layout_forward")
+  step_alg = sum(alg[k] for k in alg if k not in off_step)
+  dom = max((k for k in ph if k not in off_step), key=lambda k: ph[k])
   achieved = alg[dom] / (ph[dom] * 1e-3) / 1e9
   res = {
       "metric": "FID lookups+updates/sec (node)", "value": 2.0 * n / dt,
@@ -389,9 +404,10 @@ def main_config3(args, device):
       "dtype": "f32", "data": "synthetic",
       "config": {"workload": "config 3: %d multi-hot slots, bags ~ Poisson(50) in [1, 200], ids "
                              "Zipf(1.1) over %.3g per slot, batch %d, half SUM half MEAN pooling "
-                             "into a CONCAT layout, dim %d, FTRL; sharding_sparse_fids -> lookup -> "
-                             "fused_embedding_to_layout -> gradient -> apply_gradients" %
-                             (S, vocab, B, D),
+                             "into a CONCAT layout, dim %d, FTRL; sharding_sparse_fids -> %s -> "
+                             "gradient -> apply_gradients" %
+                             (S, vocab, B, D, "lookup -> fused_embedding_to_layout" if two_step
+                              else "fused lookup + pool (fused_lookup_to_layout)"),
                  "fids_per_step": n, "unique_fids_per_step": u, "table_rows": S * vocab,
                  "populate_s": t_pop, "fused_forward_equals_two_step": bool(same)},
       "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -399,8 +415,9 @@ def main_config3(args, device):
                    "algorithmic_bytes": alg[dom], "phase_ms": ph,
                    "phase_algorithmic_GBps": {k: alg[k] / (ph[k] * 1e-3) / 1e9 for k in ph},
                    "phase_note": "phases timed with HIP events on the launch stream outside the "
-                                 "timed region; fused_lookup_to_layout = the one-pass alternative "
-                                 "to lookup + layout_forward (not part of the step)",
+                                 "timed region; not part of the step: " + " + ".join(off_step) +
+                                 (" (the one-pass alternative)" if two_step else
+                                  " (the two-step alternative to fused_lookup_to_layout)"),
                    "step_algorithmic_GBps": step_alg / dt / 1e9,
                    "step_frac": step_alg / dt / 1e9 / HBM_PEAK_GBS},
       "cpu_baseline": None,
@@ -569,6 +586,10 @@ def main():
                   help="run the N > 1 exchange pipeline even at N = 1 (profiling aid)")
   ap.add_argument("--no-prefetch", action="store_true",
                   help="sharded pipeline: reorder each batch in line instead of one batch ahead")
+  ap.add_argument("--fused-forward", action="store_true",
+                  help="config 3: the fused lookup + pool in the step instead of lookup + "
+                       "fused_embedding_to_layout (1.98 against 1.95 ms: the update order prepared "
+                       "beside the pooling kernel slows it by what the fusion saves)")
   ap.add_argument("--config", type=int, default=0, help="2 | 3 | 4 | 5 (default: 2, or 4 when N > 1)")
   ap.add_argument("--dim", type=int, default=0, help="config 4 / --sharded: row width (default 64 / 16)")
   args = ap.parse_args()

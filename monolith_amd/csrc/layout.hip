@@ -239,78 +239,97 @@ struct GradArgs {
   int packed, sbits, bbits;
 };
 
-// One thread per use. A wave's 64 uses are consecutive fid positions of (nearly always) one
-// slice, so the feature run of the wave's first use is found once, by a search every lane runs on
-// the same values (scalar loads), and each lane walks forward from there: 14 dependent vector
-// loads per use otherwise, which made this kernel as expensive as a sort pass.
+// One thread per use; a wave owns kEnumSpan consecutive uses and walks them 64 at a time. Those
+// are consecutive fid positions of (nearly always) one slice, so the feature run of a round's
+// first use is found once — by a search every lane runs on the same values (scalar loads) in the
+// first round, and from the run the previous round ended in afterwards — and each lane walks
+// forward from there. (A 14-step search per use, then per wave and round, kept this kernel at
+// the cost of a sort pass: it is a chain of dependent loads, not bandwidth.)
+constexpr int kEnumRounds = 8;
+constexpr int kEnumSpan = 64 * kEnumRounds;
 __global__ void __launch_bounds__(256) k_layout_grad_enumerate(GradArgs a) {
   const int lane = threadIdx.x & 63;
-  for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c - lane < a.n_contrib;
-       c += (long long)gridDim.x * blockDim.x) {
-    const bool act = c < a.n_contrib;
-    const long long cc = act ? c : a.n_contrib - 1;
-    int lo = 0, hi = a.l.n_slices - 1;
-    while (lo < hi) {
-      int mid = (lo + hi + 1) >> 1;
-      if (a.gs[mid].cbase <= cc) lo = mid; else hi = mid - 1;
-    }
-    const SliceDev sc = a.l.slices[lo];
-    const GradSliceDev gs = a.gs[lo];
-    const long long local = cc - gs.cbase;
-    int b, seq, p;
-    if (sc.shared) {  // every sample scatters to the one shared run (:874-876)
-      b = (int)(local / gs.len0);
-      seq = (int)(local - (long long)b * gs.len0);
-      p = gs.p0 + seq;
-    } else {
-      p = gs.p0 + (int)local;
-      // feature run holding fid position p: last f in [f0, f0 + batch) with feature_offset[f] <= p
-      const int lo1 = __builtin_amdgcn_readfirstlane(lo);
-      const int p1 = __builtin_amdgcn_readfirstlane(p);
-      const int f01 = __builtin_amdgcn_readfirstlane(sc.f0);
-      int flo = f01, fhi = f01 + a.l.batch - 1;
-      while (flo < fhi) {  // the first lane's run (uniform)
-        int mid = (flo + fhi + 1) >> 1;
-        if (a.l.feature_offset[mid] <= p1) flo = mid; else fhi = mid - 1;
+  const long long wave = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long span0 = wave * kEnumSpan; span0 < a.n_contrib; span0 += nwaves * kEnumSpan) {
+    int carry_slice = -1, carry_f = 0;
+    for (int k = 0; k < kEnumRounds; ++k) {
+      const long long c = span0 + (long long)k * 64 + lane;
+      if (c - lane >= a.n_contrib) break;
+      const bool act = c < a.n_contrib;
+      const long long cc = act ? c : a.n_contrib - 1;
+      int lo = 0, hi = a.l.n_slices - 1;
+      while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (a.gs[mid].cbase <= cc) lo = mid; else hi = mid - 1;
       }
-      if (lo == lo1) {  // same slice, p >= p1: forward from the first lane's run
-        const int last = sc.f0 + a.l.batch - 1;
-        while (flo < last && a.l.feature_offset[flo + 1] <= p) ++flo;
-      } else {  // a wave that straddles two slices: search on its own
-        flo = sc.f0;
-        fhi = sc.f0 + a.l.batch - 1;
-        while (flo < fhi) {
-          int mid = (flo + fhi + 1) >> 1;
-          if (a.l.feature_offset[mid] <= p) flo = mid; else fhi = mid - 1;
+      const SliceDev sc = a.l.slices[lo];
+      const GradSliceDev gs = a.gs[lo];
+      const long long local = cc - gs.cbase;
+      int b, seq, p;
+      if (sc.shared) {  // every sample scatters to the one shared run (:874-876)
+        b = (int)(local / gs.len0);
+        seq = (int)(local - (long long)b * gs.len0);
+        p = gs.p0 + seq;
+        carry_slice = -1;
+      } else {
+        p = gs.p0 + (int)local;
+        // feature run holding fid position p: last f in [f0, f0 + batch) with feature_offset[f] <= p
+        const int lo1 = __builtin_amdgcn_readfirstlane(lo);
+        const int p1 = __builtin_amdgcn_readfirstlane(p);
+        const int f01 = __builtin_amdgcn_readfirstlane(sc.f0);
+        int flo = f01, fhi = f01 + a.l.batch - 1;
+        if (lo1 == carry_slice) {
+          flo = carry_f;  // the first lane's position lies at or behind the last round's last run
+        } else {
+          while (flo < fhi) {  // the first lane's run (uniform)
+            int mid = (flo + fhi + 1) >> 1;
+            if (a.l.feature_offset[mid] <= p1) flo = mid; else fhi = mid - 1;
+          }
+        }
+        if (lo == lo1) {  // same slice, p >= p1: forward from the first lane's run
+          const int last = sc.f0 + a.l.batch - 1;
+          while (flo < last && a.l.feature_offset[flo + 1] <= p) ++flo;
+        } else {  // a round that straddles two slices: search on its own
+          flo = sc.f0;
+          fhi = sc.f0 + a.l.batch - 1;
+          while (flo < fhi) {
+            int mid = (flo + fhi + 1) >> 1;
+            if (a.l.feature_offset[mid] <= p) flo = mid; else fhi = mid - 1;
+          }
+        }
+        b = flo - sc.f0;
+        seq = p - a.l.feature_offset[flo];
+        // the next round starts where lane 63 ended (only if it was still in the first lane's slice)
+        const int lo63 = __builtin_amdgcn_readlane(lo, 63);
+        carry_f = __builtin_amdgcn_readlane(flo, 63);
+        carry_slice = lo63 == lo1 ? lo1 : -1;
+      }
+      if (!act) continue;
+      uint32_t key = a.nokey;
+      const float* src = nullptr;
+      const bool firstn = sc.pooling == MONO_POOL_FIRSTN;
+      const uint64_t fo = a.l.fid_offset[p];
+      const uint32_t i1 = (uint32_t)(fo >> 32), i2 = (uint32_t)fo;
+      if (i1 < (uint32_t)a.l.n_bufs && !(firstn && seq >= sc.max_seq)) {
+        const BufDev bd = a.l.bufs[i1];
+        const long long off = (long long)i2 * bd.dim + sc.start;
+        if (off + sc.dim <= bd.floats) {
+          key = (uint32_t)(bd.gbase_u + (long long)i2 * bd.dim_u + gs.start_u);
+          if (!a.packed)
+            src = a.out_grads[sc.out_index] + (long long)b * sc.out_stride + sc.out_offset +
+                  (firstn ? seq * sc.dim : 0);
         }
       }
-      b = flo - sc.f0;
-      seq = p - a.l.feature_offset[flo];
-    }
-    if (!act) continue;
-    uint32_t key = a.nokey;
-    const float* src = nullptr;
-    const bool firstn = sc.pooling == MONO_POOL_FIRSTN;
-    const uint64_t fo = a.l.fid_offset[p];
-    const uint32_t i1 = (uint32_t)(fo >> 32), i2 = (uint32_t)fo;
-    if (i1 < (uint32_t)a.l.n_bufs && !(firstn && seq >= sc.max_seq)) {
-      const BufDev bd = a.l.bufs[i1];
-      const long long off = (long long)i2 * bd.dim + sc.start;
-      if (off + sc.dim <= bd.floats) {
-        key = (uint32_t)(bd.gbase_u + (long long)i2 * bd.dim_u + gs.start_u);
-        if (!a.packed)
-          src = a.out_grads[sc.out_index] + (long long)b * sc.out_stride + sc.out_offset +
-                (firstn ? seq * sc.dim : 0);
+      a.key[c] = key;
+      if (a.packed) {
+        a.val[c] = key == a.nokey ? 0u
+                                  : ((uint32_t)lo | ((uint32_t)b << a.sbits) |
+                                     (firstn ? (uint32_t)seq << (a.sbits + a.bbits) : 0u));
+      } else {
+        a.cslice[c] = (uint32_t)lo;
+        a.srcp[c] = src;
       }
-    }
-    a.key[c] = key;
-    if (a.packed) {
-      a.val[c] = key == a.nokey ? 0u
-                                : ((uint32_t)lo | ((uint32_t)b << a.sbits) |
-                                   (firstn ? (uint32_t)seq << (a.sbits + a.bbits) : 0u));
-    } else {
-      a.cslice[c] = (uint32_t)lo;
-      a.srcp[c] = src;
     }
   }
 }
@@ -555,19 +574,41 @@ int mono_lookup_to_layout(const mono_layout_slice* h_slices, int n_slices, void*
   std::vector<int32_t> dims(n_bufs), strides(n_bufs);
   std::vector<int64_t> floats(n_bufs);
   std::vector<const uint32_t*> slots(n_bufs);
+  // Lists that follow each other in memory and name the same table (the V2 per-feature sub-ranges
+  // of one fid_list tensor) are resolved by ONE launch: eight 9-us launches in a row otherwise.
   int64_t off = 0;
-  for (int i = 0; i < n_bufs; ++i) {
-    uint32_t* sl = (uint32_t*)slot_ws.ptr + off;
-    MONO_TRY(table_resolve_slots(h_tables[i], h_fid_lists[i], h_fid_counts[i], sl, st));
+  for (int i = 0; i < n_bufs;) {
+    int j = i + 1;
+    int64_t run = h_fid_counts[i];
+    while (j < n_bufs && h_tables[j] == h_tables[i] && h_fid_lists[j] == h_fid_lists[i] + run) {
+      run += h_fid_counts[j];
+      ++j;
+    }
+    // a table named by ONE run is looked up through its slot record: the update of these ids that
+    // follows (apply_gradients on the same fid list) then finds a lookup's prepared order
+    bool once = true;
+    for (int k = 0; k < n_bufs; ++k) once = once && (k >= i && k < j ? true : h_tables[k] != h_tables[i]);
+    const uint32_t* sl = nullptr;
+    if (once) MONO_TRY(table_lookup_slots(h_tables[i], h_fid_lists[i], run, &sl, st));
+    if (!sl) {
+      uint32_t* own = (uint32_t*)slot_ws.ptr + off;
+      MONO_TRY(table_resolve_slots(h_tables[i], h_fid_lists[i], run, own, st));
+      sl = own;
+    }
     const float* rows = nullptr;
     int dim = 0, stride = 0;
     MONO_TRY(table_row_view(h_tables[i], &rows, &dim, &stride));
-    ptrs[i] = const_cast<float*>(rows);
-    dims[i] = dim;
-    strides[i] = stride;
-    floats[i] = h_fid_counts[i] * (int64_t)dim;
-    slots[i] = sl;
-    off += (h_fid_counts[i] + 63) & ~(int64_t)63;
+    int64_t at = 0;
+    for (int k = i; k < j; ++k) {
+      ptrs[k] = const_cast<float*>(rows);
+      dims[k] = dim;
+      strides[k] = stride;
+      floats[k] = h_fid_counts[k] * (int64_t)dim;
+      slots[k] = sl + at;
+      at += h_fid_counts[k];
+    }
+    off += (run + 63) & ~(int64_t)63;
+    i = j;
   }
   HostPlan hp;
   MONO_TRY(build_plan(h_slices, n_slices, ptrs.data(), dims.data(), floats.data(), n_bufs,
@@ -727,7 +768,8 @@ int mono_embedding_to_layout_grad(const mono_layout_slice* h_slices, int n_slice
   a.nokey = (uint32_t)n_units;
   a.key_unit = (int)unit;
   a.packed = packed ? 1 : 0; a.sbits = sbits; a.bbits = bbits;
-  hipLaunchKernelGGL(k_layout_grad_enumerate, dim3(grid_for(nc, 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(k_layout_grad_enumerate, dim3(grid_for(nc, 4 * kEnumSpan, 256 * 64)), dim3(256), 0, st,
+                     a);
   MONO_HIP(hipGetLastError());
   const int end_bit = bits_for_l((uint64_t)n_units);  // nokey = n_units sorts last
   const size_t tmp = sort_pairs_tmp_bytes((size_t)nc, end_bit);

@@ -129,6 +129,10 @@ int segment_set_sum_planned(const uint32_t* skeys, const uint32_t* sidx, int64_t
 // row_floats floats). The view is valid until the next call that can grow the table.
 int table_resolve_slots(void* table, const int64_t* ids, int64_t n, uint32_t* slots, hipStream_t st);
 int table_row_view(void* table, const float** rows, int* dim, int* row_floats);
+// the same slots, taken as a LOOKUP of the table (slot record + prepared update order for the
+// update of the same ids that follows); *slots = nullptr when the record is switched off
+int table_lookup_slots(void* table, const int64_t* ids, int64_t n, const uint32_t** slots,
+                       hipStream_t st);
 
 }  // namespace mono
 

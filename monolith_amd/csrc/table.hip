@@ -2198,7 +2198,9 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
     else if (gather_ilp <= 4) MONO_GATHER(LPR, 4);          \
     else MONO_GATHER(LPR, 8);                               \
   } while (0)
-  if (D % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) {
+  if (!out) {
+    // slots only (table_lookup_slots: the fused lookup + pool gathers the rows itself)
+  } else if (D % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) {
     if (D <= 16) MONO_GATHER_L(4);
     else if (D <= 32) MONO_GATHER_L(8);
     else MONO_GATHER_L(16);
@@ -2688,7 +2690,8 @@ int segment_set_sum_planned(const uint32_t* skeys, const uint32_t* sidx, int64_t
 // Slots of `ids` (kNoSlot for ids the table does not hold), nothing else touched: the resolve
 // half of the fused lookup + pool (layout.hip, mono_lookup_to_layout).
 __global__ void __launch_bounds__(256) k_resolve(TableDev t, const int64_t* __restrict__ ids, int64_t n,
-                                                 uint32_t* __restrict__ slots) {
+                                                 uint32_t* __restrict__ slots,
+                                                 int64_t* __restrict__ cache_ids = nullptr) {
   const int sub = lane_sub(), gshift = lane_gshift();
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
   for (int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8) * kIlpP; i0 < n;
@@ -2709,7 +2712,10 @@ __global__ void __launch_bounds__(256) k_resolve(TableDev t, const int64_t* __re
       const uint32_t sl = group_find_pre(t, key[q], b[q], k0[q], sub, gshift);
       if (sub == q) my_slot = sl;
     }
-    if (i0 + sub < n) slots[i0 + sub] = my_slot;
+    if (i0 + sub < n) {
+      slots[i0 + sub] = my_slot;
+      if (cache_ids) cache_ids[i0 + sub] = mine;
+    }
   }
 }
 
@@ -2719,6 +2725,59 @@ int table_resolve_slots(void* table, const int64_t* ids, int64_t n, uint32_t* sl
   Table* t = (Table*)table;
   hipLaunchKernelGGL(k_resolve, dim3(grid_for(n, 32 * kIlpP)), dim3(256), 0, st, t->d, ids, n, slots);
   MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+// mono_table_lookup; out == nullptr: resolve and record the slots only (the caller reads
+// t->cache_slots and gathers the rows itself), with the same book-keeping, so that the update
+// which follows finds the slot record / the prepared order of a lookup.
+static int lookup_impl(Table* t, const int64_t* ids, int64_t n, float* out, hipStream_t st) {
+  const bool aligned = ((uintptr_t)out & 15) == 0;
+  if (slot_cache_enabled() && n < (int64_t)0xFFFFFFF0ll) {
+    if (n > t->cache_cap) {  // grows once per batch size; (re)allocation synchronises
+      if (t->cache_ids) (void)hipFree(t->cache_ids);
+      if (t->cache_slots) (void)hipFree(t->cache_slots);
+      t->cache_ids = nullptr; t->cache_slots = nullptr; t->cache_cap = 0; t->cache_n = 0;
+      MONO_HIP(hipMalloc((void**)&t->cache_ids, (size_t)n * sizeof(int64_t)));
+      MONO_HIP(hipMalloc((void**)&t->cache_slots, (size_t)n * sizeof(uint32_t)));
+      t->cache_cap = n;
+    }
+    t->cache_n = n;
+  } else {
+    t->cache_n = 0;
+  }
+  MONO_REQUIRE(out || t->cache_n, "lookup_impl: a slots-only lookup needs the slot record");
+  // a second lookup with no update in between: not the training pattern (any more)
+  if (++t->lookups_since_update > 1) t->expect_update = false;
+  t->prep.n = 0;  // the record it was built from is being overwritten
+  if (t->cache_n && prep_mode() != 0 && (t->expect_update || prep_mode() == 2))
+    return lookup_prepared(t, ids, n, out, aligned, st);
+  if (!out) {
+    hipLaunchKernelGGL(k_resolve, dim3(grid_for(n, 32 * kIlpP)), dim3(256), 0, st, t->d, ids, n,
+                       t->cache_slots, t->cache_ids);
+    MONO_HIP(hipGetLastError());
+    return 0;
+  }
+  int64_t* ci = t->cache_n ? t->cache_ids : nullptr;
+  uint32_t* cs = t->cache_n ? t->cache_slots : nullptr;
+  if (t->d.dim % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) launch_lookup<4>(t, ids, n, out, st, ci, cs);
+  else if (t->d.dim % 2 == 0 && t->d.row_floats % 2 == 0 && aligned) launch_lookup<2>(t, ids, n, out, st, ci, cs);
+  else launch_lookup<1>(t, ids, n, out, st, ci, cs);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+// The slots of `ids` as a LOOKUP of the table: *slots points into the table's slot record (valid
+// until the table's next lookup), and an update of the same ids that follows is served like one
+// that follows mono_table_lookup. nullptr in *slots: the record is switched off, resolve plainly.
+int table_lookup_slots(void* table, const int64_t* ids, int64_t n, const uint32_t** slots,
+                       hipStream_t st) {
+  MONO_REQUIRE(table && slots, "table_lookup_slots: null argument");
+  *slots = nullptr;
+  Table* t = (Table*)table;
+  if (n == 0 || !slot_cache_enabled() || n >= (int64_t)0xFFFFFFF0ll) return 0;
+  MONO_TRY(lookup_impl(t, ids, n, nullptr, st));
+  *slots = t->cache_slots;
   return 0;
 }
 
@@ -2908,34 +2967,7 @@ int mono_table_lookup(void* table, const int64_t* ids, int64_t n, float* out, vo
   MONO_REQUIRE(table, "mono_table_lookup: null table");
   if (n == 0) return 0;
   MONO_REQUIRE(ids && out, "mono_table_lookup: null buffer");
-  Table* t = (Table*)table;
-  hipStream_t st = (hipStream_t)stream;
-  const bool aligned = ((uintptr_t)out & 15) == 0;
-  if (slot_cache_enabled() && n < (int64_t)0xFFFFFFF0ll) {
-    if (n > t->cache_cap) {  // grows once per batch size; (re)allocation synchronises
-      if (t->cache_ids) (void)hipFree(t->cache_ids);
-      if (t->cache_slots) (void)hipFree(t->cache_slots);
-      t->cache_ids = nullptr; t->cache_slots = nullptr; t->cache_cap = 0; t->cache_n = 0;
-      MONO_HIP(hipMalloc((void**)&t->cache_ids, (size_t)n * sizeof(int64_t)));
-      MONO_HIP(hipMalloc((void**)&t->cache_slots, (size_t)n * sizeof(uint32_t)));
-      t->cache_cap = n;
-    }
-    t->cache_n = n;
-  } else {
-    t->cache_n = 0;
-  }
-  // a second lookup with no update in between: not the training pattern (any more)
-  if (++t->lookups_since_update > 1) t->expect_update = false;
-  t->prep.n = 0;  // the record it was built from is being overwritten
-  if (t->cache_n && prep_mode() != 0 && (t->expect_update || prep_mode() == 2))
-    return lookup_prepared(t, ids, n, out, aligned, st);
-  int64_t* ci = t->cache_n ? t->cache_ids : nullptr;
-  uint32_t* cs = t->cache_n ? t->cache_slots : nullptr;
-  if (t->d.dim % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) launch_lookup<4>(t, ids, n, out, st, ci, cs);
-  else if (t->d.dim % 2 == 0 && t->d.row_floats % 2 == 0 && aligned) launch_lookup<2>(t, ids, n, out, st, ci, cs);
-  else launch_lookup<1>(t, ids, n, out, st, ci, cs);
-  MONO_HIP(hipGetLastError());
-  return 0;
+  return lookup_impl((Table*)table, ids, n, out, (hipStream_t)stream);
 }
 
 int mono_table_assign(void* table, void* filter, const int64_t* ids, const float* values, int64_t n,
