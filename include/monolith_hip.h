@@ -227,7 +227,14 @@ int mono_tables_fused_apply_gradient(void* const* tables, void* const* filters, 
                                      int64_t global_step, int N, int enable_grad_accumulation,
                                      void* stream);
 
-/* ---- routing / exchange ops ---- */
+/* ---- routing / exchange ops ----
+ * SURVEY.md 8(b) also sketches mono_comm_init / mono_a2a_ids / mono_a2a_rows / mono_a2a_grads. They
+ * are deliberately NOT part of this ABI: the four all-to-alls of a step (reference
+ * distributed_ps_sync.py:170-193,230-283,369-496, hvd.alltoall / bps.alltoall) are issued by the
+ * host layer through torch.distributed.all_to_all_single, whose "nccl" backend IS RCCL over xGMI;
+ * this library carries no communication dependency (INTEGRATION.md 4 list the exact
+ * torch calls). What the exchange needs from the device side is below: the reorder that produces
+ * the send buffers and split sizes, the gathers on either side of the row exchange. */
 /* ops/fused_reorder_by_indices.cc:36-112 + distribution_ops.py:255-272. inputs: M device id
  * arrays (host array of device pointers); shard_rule 0 = floormod(id, N), 1 = 1 + floormod(id, N-1).
  * out_ids has room for sum(lens) ids; *h_n_unique = ids written; out_offsets: M device int32

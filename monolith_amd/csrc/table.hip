@@ -1354,12 +1354,13 @@ constexpr int kLStage4 = kLTileFloats / 4 / kLoaders;  // 8 float4 per loader th
 constexpr int kLMaxRows = 2 * kLoaders;        // rows per tile (two prefetched indices per thread)
 constexpr int kLIdxRing = 8;
 
-template <int OPTK, int MODE>
-// (two workgroups per CU for the stateless sum of the layout gradient — it runs hundreds of
-// thousands of rows through these chains and nothing else competes for the CUs' registers; beside
-// the table's k_apply the second workgroup costs the sub-group kernel more than it gains:
-// config 2 355 -> 396 us per step)
-__global__ void __launch_bounds__(256, MODE == MODE_SET_SUM ? 2 : 1) k_apply_long(TableDev t, ApplyArgs a) {
+// OCC: workgroups per CU the register budget is set for. Two for the layout gradient's sums (it
+// runs hundreds of thousands of rows through these chains at dim 16 and nothing else competes for
+// the CUs' registers); one beside the table's k_apply and for the exchange's gradient sum, where
+// the second workgroup costs the kernel that carries the traffic more than it gains (config 2:
+// 355 -> 396 us per step, config 4: 1.07 -> 1.12 ms).
+template <int OPTK, int MODE, int OCC = 1>
+__global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a) {
   __shared__ __attribute__((aligned(16))) float tile[2][kLTileFloats];
   __shared__ uint32_t idxs[kLIdxRing][kLMaxRows];
   __shared__ uint32_t s_qi;
@@ -1889,7 +1890,10 @@ static void launch_long_m(const Table* t, const ApplyArgs& a, unsigned grid, hip
       hipLaunchKernelGGL((k_apply_long<OPTK, MODE_OPT_SEQ>), dim3(grid), dim3(256), 0, st, t->d, a);
       break;
     case MODE_SET_SUM:
-      hipLaunchKernelGGL((k_apply_long<OPTK, MODE_SET_SUM>), dim3(grid), dim3(256), 0, st, t->d, a);
+      if (a.src_tab || a.src_ptrs)
+        hipLaunchKernelGGL((k_apply_long<OPTK, MODE_SET_SUM, 2>), dim3(grid), dim3(256), 0, st, t->d, a);
+      else
+        hipLaunchKernelGGL((k_apply_long<OPTK, MODE_SET_SUM>), dim3(grid), dim3(256), 0, st, t->d, a);
       break;
     default:
       hipLaunchKernelGGL((k_apply_long<OPTK, MODE_OPT_DEDUP>), dim3(grid), dim3(256), 0, st, t->d, a);
