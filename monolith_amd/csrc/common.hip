@@ -36,6 +36,42 @@ int Workspace::ensure(size_t need) {
   return 0;
 }
 
+// ---- pinned staging ring for small host -> device uploads ----
+namespace {
+constexpr int kUpSlots = 32;
+constexpr size_t kUpSlotBytes = 64 * 1024;
+struct UploadRing {
+  char* base = nullptr;
+  hipEvent_t ev[kUpSlots] = {};
+  bool used[kUpSlots] = {};
+  int next = 0;
+};
+UploadRing g_up;
+}  // namespace
+
+int upload_async(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return 0;
+  if (bytes > kUpSlotBytes) {
+    MONO_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+    return 0;
+  }
+  if (!g_up.base) {  // (one host thread per GPU; the ring lives until the process ends)
+    MONO_HIP(hipHostMalloc((void**)&g_up.base, kUpSlots * kUpSlotBytes, hipHostMallocPortable));
+    for (int i = 0; i < kUpSlots; ++i)
+      MONO_HIP(hipEventCreateWithFlags(&g_up.ev[i], hipEventDisableTiming));
+  }
+  const int i = g_up.next;
+  g_up.next = (i + 1) % kUpSlots;
+  // the slot's previous copy (32 uploads ago) must have left the staging memory
+  if (g_up.used[i]) MONO_HIP(hipEventSynchronize(g_up.ev[i]));
+  char* slot = g_up.base + (size_t)i * kUpSlotBytes;
+  memcpy(slot, src_host, bytes);
+  MONO_HIP(hipMemcpyAsync(dst_dev, slot, bytes, hipMemcpyHostToDevice, st));
+  MONO_HIP(hipEventRecord(g_up.ev[i], st));
+  g_up.used[i] = true;
+  return 0;
+}
+
 void Workspace::release() {
   if (ptr) (void)hipFree(ptr);
   ptr = nullptr;

@@ -482,8 +482,8 @@ static int upload_plan(const HostPlan& hp, const void* const* h_outs, int n_outs
   for (size_t i = 0; i < pieces.size(); ++i)
     if (pieces[i].bytes) memcpy(image.data() + off[i], pieces[i].ptr, pieces[i].bytes);
   char* p = (char*)g_lws.ptr;
-  // pageable source: hipMemcpyAsync stages it before returning, so `image` may be reused
-  if (total) MONO_HIP(hipMemcpyAsync(p, image.data(), total, hipMemcpyHostToDevice, st));
+  // (through the pinned staging ring: the call enqueues and returns, `image` may be reused)
+  MONO_TRY(upload_async(p, image.data(), total, st));
   dp->slices = (SliceDev*)(p + off[0]);
   dp->groups = (GroupDev*)(p + off[1]);
   dp->bufs = (BufDev*)(p + off[2]);

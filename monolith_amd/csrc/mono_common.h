@@ -76,6 +76,13 @@ struct Workspace {
   void release();
 };
 
+// common.hip: copy a small host array (per-call metadata: descriptors, plans) to the device without
+// blocking the host. hipMemcpyAsync from pageable memory waits until the copy has been carried out,
+// behind whatever the stream's hardware queue holds (4 queues per process: that can be another
+// stream's kernels — 150 us per reorder in the sharded step); here the bytes go through a ring of
+// pinned staging slots first, so the call only enqueues. Larger than a slot: the plain copy.
+int upload_async(void* dst_dev, const void* src_host, size_t bytes, hipStream_t st);
+
 // sort.hip: stable LSD radix sort of (uint32 key, uint32 value) pairs on key bits [0, end_bit).
 // vin == nullptr sorts the identity permutation (values = input positions). kin / vin are not
 // modified; `tmp` needs sort_pairs_tmp_bytes(n, end_bit) bytes of device scratch.

@@ -973,7 +973,7 @@ static int reorder_begin(const int64_t* const* inputs, const int64_t* h_lens, in
   int32_t* dims = (int32_t*)(base + off_dims);
   int32_t* scan = (int32_t*)(base + off_scan);
   int32_t* hist = (int32_t*)(base + off_hist);
-  MONO_HIP(hipMemcpyAsync(d_sm, sm.data(), sizeof(SlotMeta) * M, hipMemcpyHostToDevice, st));
+  MONO_TRY(upload_async(d_sm, sm.data(), sizeof(SlotMeta) * M, st));
   MONO_HIP(hipMemsetAsync(hfirst, 0xFF, c_al * 4, st));
   MONO_HIP(hipMemsetAsync(hist, 0, hist_al * 4, st));
   ReorderArgs a{M, N, shard_rule, total};
@@ -1135,9 +1135,9 @@ int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* 
   uint32_t* sidx2 = (uint32_t*)(base + off_sidx2);
   int32_t* hist = (int32_t*)(base + off_hist);
   int32_t* start = (int32_t*)(base + off_start);
-  MONO_HIP(hipMemcpyAsync(d_sm, sm.data(), sizeof(SlotMeta) * M, hipMemcpyHostToDevice, st));
-  MONO_HIP(hipMemcpyAsync(d_rm, rm.data(), sizeof(RunMeta) * M, hipMemcpyHostToDevice, st));
-  MONO_HIP(hipMemcpyAsync(d_oi, h_out_index, (size_t)M * ps_num * 4, hipMemcpyHostToDevice, st));
+  MONO_TRY(upload_async(d_sm, sm.data(), sizeof(SlotMeta) * M, st));
+  MONO_TRY(upload_async(d_rm, rm.data(), sizeof(RunMeta) * M, st));
+  MONO_TRY(upload_async(d_oi, h_out_index, (size_t)M * ps_num * 4, st));
   const dim3 blk(256);
   if (total_runs > 0)
     hipLaunchKernelGGL(k_shard_feature_offsets, dim3(grid_for(total_runs, 256)), blk, 0, st, d_rm, M,
