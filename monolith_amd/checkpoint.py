@@ -81,7 +81,12 @@ def masked_crc32c(data: bytes) -> int:
 
 def read_records(path: str, verify: bool = True) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
   """(file image uint8, payload offsets, payload lengths); raises on a bad frame / crc."""
-  buf = np.fromfile(path, dtype=np.uint8)
+  return scan_records(np.fromfile(path, dtype=np.uint8), verify)
+
+
+def scan_records(buf: np.ndarray, verify: bool = True) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+  """The same over a record stream already in memory (uint8 array)."""
+  buf = np.ascontiguousarray(buf, dtype=np.uint8)
   if buf.size == 0:
     return buf, np.zeros(0, np.int64), np.zeros(0, np.int64)
   fn = _lib.lib.mono_tfrecord_scan
@@ -446,6 +451,126 @@ def read_shards(basename: str, layout: DumpLayout, verify: bool = True):
     return (np.zeros(0, np.int64), np.zeros((0, layout.row_floats), np.float32),
             np.zeros(0, np.uint32))
   return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+
+
+# ============================================================================ multi-table dumps
+# ops/multi_hash_table_save_restore_ops.cc:143-213 (save), :264-352 (restore). Per shard i of n:
+#   <basename>-%05d-of-%05d        the EntryDumps of ALL member tables, table after table, as a
+#                                  TFRecord stream under RecordWriterOptions::SNAPPY_COMPRESSION
+#   <basename>.meta-%05d-of-%05d   one plain TFRecord per table: MultiHashTableMetadata
+#                                  {1: string table_name, 2: uint64 num_entries}
+#                                  (embedding_hash_table.proto:135-138)
+# TensorFlow's snappy record stream (third-party: tensorflow/core/lib/io/snappy/
+# snappy_outputbuffer.cc at the reference's pinned TensorFlow 2.4.0, absent here) is restated from
+# its published form: the framed records are cut into input blocks of at most 256 KiB
+# (RecordWriterOptions' snappy input buffer), each written as a 4-byte big-endian length of the
+# compressed block followed by the raw snappy block. The reference ships no multi-table dump, so
+# the BYTES are parity-unpinned (stated in the tests); the reader accepts any block size.
+SNAPPY_BLOCK = 256 * 1024
+
+
+def _snappy():
+  import pyarrow as pa  # raw snappy block codec
+  return pa.Codec("snappy")
+
+
+def snappy_stream_compress(raw: bytes, block: int = SNAPPY_BLOCK) -> bytes:
+  codec, out = _snappy(), []
+  for lo in range(0, len(raw), block):
+    c = codec.compress(raw[lo:lo + block]).to_pybytes()
+    out.append(len(c).to_bytes(4, "big"))
+    out.append(c)
+  return b"".join(out)
+
+
+def snappy_stream_decompress(data: bytes) -> bytes:
+  codec, out, p = _snappy(), [], 0
+  while p < len(data):
+    if p + 4 > len(data):
+      raise ValueError("snappy record stream: truncated block length")
+    n = int.from_bytes(data[p:p + 4], "big")
+    p += 4
+    if n == 0 or p + n > len(data):
+      raise ValueError("snappy record stream: truncated block")
+    blk = data[p:p + n]
+    size, _ = _read_varint(blk, 0)  # a raw snappy block opens with its uncompressed length
+    out.append(codec.decompress(blk, decompressed_size=size).to_pybytes())
+    p += n
+  return b"".join(out)
+
+
+def sharded_meta_name(basename: str, idx: int, total: int) -> str:
+  return "%s.meta-%05d-of-%05d" % (basename, idx, total)
+
+
+def encode_multi_meta(table_name: str, num_entries: int) -> bytes:
+  nb = table_name.encode()
+  return b"\x0a" + _varint(len(nb)) + nb + b"\x10" + _varint(int(num_entries))
+
+
+def decode_multi_meta(b: bytes) -> Tuple[str, int]:
+  name, n = "", 0
+  for fno, wt, val in _parse_fields(bytes(b)):
+    if fno == 1 and wt == 2:
+      name = bytes(val).decode()
+    elif fno == 2 and wt == 0:
+      n = int(val)
+  return name, n
+
+
+def _frame_one(payload: bytes) -> bytes:
+  return frame_records(np.frombuffer(payload, np.uint8).reshape(1, -1)).tobytes()
+
+
+def write_multi_shards(basename: str, tables, nshards: int) -> None:
+  """tables: [(name, DumpLayout, ids, rows, ts)] in the table set's order."""
+  os.makedirs(os.path.dirname(os.path.abspath(basename)), exist_ok=True)
+  nshards = max(1, int(nshards))
+  for i in range(nshards):
+    data, meta = [], []
+    for name, layout, ids, rows, ts in tables:
+      ids = np.asarray(ids, np.int64)
+      sel = np.nonzero(np.mod(ids, nshards) == i)[0] if nshards > 1 else np.arange(len(ids))
+      if len(sel):
+        for group in layout.encode(ids[sel], np.asarray(rows)[sel], np.asarray(ts)[sel]):
+          data.append(frame_records(group).tobytes())
+      meta.append(_frame_one(encode_multi_meta(name, len(sel))))
+    for name, payload in ((sharded_name(basename, i, nshards), snappy_stream_compress(b"".join(data))),
+                          (sharded_meta_name(basename, i, nshards), b"".join(meta))):
+      tmp = "%s-tmp-%d" % (name, os.getpid())
+      with open(tmp, "wb") as f:
+        f.write(payload)
+      os.replace(tmp, name)
+
+
+def read_multi_shards(basename: str, layouts: Dict[str, "DumpLayout"], verify: bool = True):
+  """{table name: (ids, rows, ts)} for the tables of `layouts` found in the dump; tables of the
+  dump that `layouts` does not name are skipped record by record, as the reference does."""
+  files = sorted(f for f in glob.glob(glob.escape(basename) + "-*")
+                 if re.fullmatch(r".*-\d{5}-of-\d{5}", f))
+  if not files:
+    raise FileNotFoundError("Unable to find the dump files for: " + basename)
+  totals = {int(f[-5:]) for f in files}
+  if len(totals) != 1 or len(files) != totals.pop():
+    raise ValueError("inconsistent shard files for " + basename)
+  parts: Dict[str, list] = {}
+  for i, f in enumerate(files):
+    with open(f, "rb") as fh:
+      buf = np.frombuffer(snappy_stream_decompress(fh.read()), np.uint8)
+    buf, off, ln = scan_records(buf, verify)
+    mbuf, moff, mln = read_records(sharded_meta_name(basename, i, len(files)), verify)
+    at = 0
+    for o, l in zip(moff.tolist(), mln.tolist()):
+      name, n = decode_multi_meta(mbuf[o:o + l].tobytes())
+      if at + n > len(off):
+        raise ValueError("Couldn't read all of checkpoint shard %d" % i)
+      if name in layouts and n:
+        parts.setdefault(name, []).append(layouts[name].decode(buf, off[at:at + n], ln[at:at + n]))
+      at += n
+    if at != len(off):
+      raise ValueError("Couldn't read all of checkpoint shard %d" % i)
+  return {name: tuple(np.concatenate([p[k] for p in ps]) for k in range(3))
+          for name, ps in parts.items()}
 
 
 # ============================================================================ hash-filter dumps

@@ -368,9 +368,11 @@ class HashTable(BaseHashTable):
     k = int(cnt.value)
     return ids[:k], rows[:k], ts[:k]
 
-  def restore_from_tensor(self, ids, rows, ts) -> "HashTable":
-    """Clear + upsert of full entries (ops/hash_table_restore_op.cc:82-131)."""
-    self.clear()
+  def restore_from_tensor(self, ids, rows, ts, clear: bool = True) -> "HashTable":
+    """Clear + upsert of full entries (ops/hash_table_restore_op.cc:82-131); clear=False is the
+    multi-table restore, which upserts into the tables as they are."""
+    if clear:
+      self.clear()
     ids = _ids(ids)
     rows = _f32(rows)
     ts = ts.to(device=_dev(), dtype=torch.int32).contiguous()

@@ -191,9 +191,39 @@ class MultiHashTable(BaseMultiTypeHashTable):
         torch.as_tensor(slot_to_value[n]).to(device=dev, dtype=torch.float32)
         if n in slot_to_value else empty for n in self._table_names])
 
-  def save(self, basename):
-    raise NotImplementedError("multi-table dumps (Snappy record files) are not implemented; "
-                              "save the member tables with HashTable.save")
+  def save(self, basename) -> "MultiHashTable":
+    """multi_hash_table_ops.py:379-385 -> MultiHashTableSaveOp (ops/multi_hash_table_save_restore_ops.cc:
+    99-232): every member table's entries, save-time expiry applied, into the snappy record files
+    <basename>-%05d-of-%05d plus the per-table counts in <basename>.meta-%05d-of-%05d."""
+    from monolith_amd import checkpoint
+    dumps, total = [], 0
+    for name, t in zip(self._table_names, self._tables):
+      if t._table.serving:
+        raise RuntimeError("ServingEntryAccessor doesn't support Save")
+      ids, rows, ts = t.save_as_tensor(apply_expiry=True)
+      dumps.append((name, checkpoint.DumpLayout.from_table_config(t._table.config),
+                    ids.cpu().numpy(), rows.cpu().numpy(), ts.cpu().numpy().astype("uint32")))
+      total += int(ids.numel())
+    saver_parallel = getattr(self._tables[0], "_saver_parallel", -1) if self._tables else -1
+    checkpoint.write_multi_shards(str(basename), dumps,
+                                  checkpoint.pick_nshards(total, saver_parallel))  # PickNshards :214-222
+    return self._copy()
 
-  def restore(self, basename):
-    raise NotImplementedError("multi-table dumps (Snappy record files) are not implemented")
+  def restore(self, basename) -> "MultiHashTable":
+    """multi_hash_table_ops.py:387-390 -> MultiHashTableRestoreOp (:232-352): entries are upserted
+    into the member tables by table NAME (no clear, unlike the single-table restore op); tables of
+    the dump this set does not have are skipped, tables the dump does not have stay as they are."""
+    from monolith_amd import checkpoint
+    import numpy as np
+    layouts = {name: checkpoint.DumpLayout.from_table_config(t._table.config)
+               for name, t in zip(self._table_names, self._tables)}
+    found = checkpoint.read_multi_shards(str(basename), layouts)
+    for name, t in zip(self._table_names, self._tables):
+      if name not in found:
+        continue
+      ids, rows, ts = found[name]
+      if t._table.serving:
+        rows = np.ascontiguousarray(rows[:, :t._table.dim])
+      t.restore_from_tensor(torch.from_numpy(ids), torch.from_numpy(rows),
+                            torch.from_numpy(ts.astype("int64")), clear=False)
+    return self._copy()

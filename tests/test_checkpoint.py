@@ -110,6 +110,45 @@ def test_write_and_read_shards_roundtrip(tmp_path):
     ck.read_shards(base, layout)
 
 
+def test_multi_table_dump_roundtrip(tmp_path):
+  """Multi-table dumps (ops/multi_hash_table_save_restore_ops.cc): snappy record stream + plain
+  metadata records, several shards, a table the reader does not know (skipped by its entry count)
+  and one the dump does not hold. The reference ships no such file, so the BYTES are
+  parity-unpinned: what is checked is the framing restated from TensorFlow's published snappy
+  record format (block = 4-byte big-endian compressed length + raw snappy block, blocks of at
+  most 256 KiB of input), the metadata message against its proto definition, and the round trip."""
+  raw = os.urandom(1000) + b"abc" * 300000  # three blocks
+  z = ck.snappy_stream_compress(raw)
+  assert ck.snappy_stream_decompress(z) == raw
+  n0 = int.from_bytes(z[:4], "big")
+  assert 0 < n0 < ck.SNAPPY_BLOCK and z[4] == 0x80 and z[5] == 0x80 and z[6] == 0x10  # varint 262144
+  with pytest.raises(ValueError):
+    ck.snappy_stream_decompress(z[:-3])
+  assert ck.encode_multi_meta("table_a", 12345).hex() == "0a077461626c655f6110b960"
+  assert ck.decode_multi_meta(ck.encode_multi_meta("t", 0)) == ("t", 0)
+  la = ck.DumpLayout([(3, ck.ADAGRAD)])
+  lb = ck.DumpLayout([(1, ck.FTRL), (4, ck.SGD)])
+  rng = np.random.Generator(np.random.PCG64(9))
+  def mk(layout, n):
+    return (rng.integers(-2**62, 2**62, n), rng.normal(0, 1, (n, layout.row_floats)).astype(np.float32),
+            rng.choice([0, 127, 128, 1_700_000_000], n).astype(np.uint32))
+  a, b, c = mk(la, 3000), mk(lb, 0), mk(lb, 700)
+  base = str(tmp_path / "d" / "MonolithMultiHashTable_x")
+  ck.write_multi_shards(base, [("a", la) + a, ("b", lb) + b, ("c", lb) + c], 3)
+  assert sorted(os.listdir(tmp_path / "d")) == sorted(
+      ["MonolithMultiHashTable_x-%05d-of-00003" % i for i in range(3)] +
+      ["MonolithMultiHashTable_x.meta-%05d-of-00003" % i for i in range(3)])
+  got = ck.read_multi_shards(base, {"a": la, "c": lb, "zzz": la})
+  assert sorted(got) == ["a", "c"]
+  for name, (ids, rows, ts) in (("a", a), ("c", c)):
+    i2, r2, t2 = got[name]
+    o1, o2 = np.argsort(ids), np.argsort(i2)
+    assert np.array_equal(ids[o1], i2[o2]) and np.array_equal(ts[o1], t2[o2])
+    assert np.array_equal(rows[o1].view(np.uint32), r2[o2].view(np.uint32))
+  got = ck.read_multi_shards(base, {"c": lb})  # "a" skipped by count, "b" empty
+  assert sorted(got) == ["c"] and len(got["c"][0]) == 700
+
+
 @pytest.mark.gpu
 def test_restore_reference_dumps_into_hip_table_and_save_again(tmp_path):
   import torch

@@ -76,5 +76,31 @@ def test_raw_api_matches_oracle():
     assert np.array_equal(out[k].cpu().numpy().view(np.uint32), model[k].lookup(probe).view(np.uint32))
   t2 = t.raw_assign(t.get_ragged_id({"b": _id([7, 8])}), _value([1, 2, 3, 4]))
   assert t2.lookup({"b": _id([8, 7])})["b"].cpu().tolist() == [[3, 4], [1, 2]]
-  with pytest.raises(NotImplementedError):
-    t.save("x")
+  with pytest.raises(NotImplementedError):  # declared and unimplemented in the reference too
+    t.lookup_entry({"b": _id([7])})
+
+
+def test_save_restore(tmp_path):
+  """multi_hash_table_ops_test.py:109-150: three tables saved; a set with slot0 / slot2 / slot3
+  restores slot0 and slot2 by name, ignores slot1, leaves slot3 empty."""
+  import os
+  t0 = mht.MultiHashTable.from_configs({"slot0": _cfg(1), "slot1": _cfg(2), "slot2": _cfg(2)},
+                                       name_suffix="sr0")
+  t0 = t0.assign_add({"slot0": (_id([0, 1]), _value([[1], [2]])),
+                      "slot1": (_id([2, 3, 4, 5]), _value([[1, 2], [2, 3], [3, 4], [4, 5]])),
+                      "slot2": (_id([6, 7, 8, 9, 10]),
+                                _value([[1, 1], [2, 2], [3, 3], [4, 4], [5, 5]]))})
+  basename = os.path.join(str(tmp_path), "test_save_restore", t0.shared_name)
+  t0 = t0.save(basename)
+  assert sorted(os.listdir(os.path.dirname(basename))) == [
+      t0.shared_name + "-00000-of-00001", t0.shared_name + ".meta-00000-of-00001"]
+  t1 = mht.MultiHashTable.from_configs({"slot0": _cfg(1), "slot2": _cfg(2), "slot3": _cfg(3)},
+                                       name_suffix="sr1")
+  t1 = t1.restore(basename)
+  out = t1.lookup({"slot0": _id([0, 1]), "slot2": _id([6, 7, 8, 9, 10]), "slot3": _id([6])})
+  assert out["slot0"].cpu().tolist() == [[1], [2]]
+  assert out["slot2"].cpu().tolist() == [[1, 1], [2, 2], [3, 3], [4, 4], [5, 5]]
+  assert out["slot3"].cpu().tolist() == [[0, 0, 0]]
+  # no clear: what the set held before a restore stays (MultiHashTableRestoreOp upserts)
+  t1 = t1.assign_add({"slot0": (_id([77]), _value([[5]]))}).restore(basename)
+  assert t1.lookup({"slot0": _id([77, 0])})["slot0"].cpu().tolist() == [[5], [1]]
