@@ -123,12 +123,19 @@ struct Table {
     char* q_base = nullptr;
     int mode_class = -1;          // what k_classify was run for (-1: not run)
     hipStream_t stream = nullptr;
-    hipEvent_t ev_probe = nullptr, ev_ready = nullptr, ev_verify = nullptr;
+    hipEvent_t ev_probe = nullptr, ev_ready = nullptr, ev_verify = nullptr, ev_gated = nullptr;
     // row gather of the prepared lookup: throttled (the update follows at once and waits for the
     // order) or at full depth (the order is ready long before the update asks for it)
     bool gather_full = false;
     int slack_run = 0, full_backoff = 0, full_backoff_len = 64;
-    uint32_t* d_flags = nullptr;  // [0] ids the lookup did not find  [1] positions k_verify found changed
+    // [0] ids the lookup did not find  [1] positions k_verify found changed (running count).
+    // [0] is WRITTEN by k_verify: the sum of the per-workgroup miss counts the last k_probe left in
+    // d_blk_miss (plain stores, no atomics: with a hash filter 5 % of a batch misses, and 85 k
+    // atomics on one word made k_probe 198 us instead of 42) — exactly that lookup's count,
+    // whatever happened to the lookups before it.
+    uint32_t* d_flags = nullptr;
+    uint32_t* d_blk_miss = nullptr;  // [kProbeMaxBlocks]
+    int probe_blocks = 0;
     uint32_t* h_flags = nullptr;  // pinned host copy
     uint32_t seen_changed = 0;    // d_flags[1] as of the last read-back (it only grows)
     bool chain_pending = false;   // a sort + classify chain was launched and the caller's stream
@@ -371,12 +378,16 @@ __global__ void __launch_bounds__(256) k_lookup(TableDev t, const int64_t* __res
 // and records the slot of every position, k_gather_rows copies the rows. Together they move what
 // k_lookup moves plus a re-read of the 4-byte slots.
 constexpr int kIlpP = 8;  // one id per lane of the sub-group
+constexpr int kProbeMaxBlocks = 4096;
 __global__ void __launch_bounds__(256) k_probe(TableDev t, const int64_t* __restrict__ ids, int64_t n,
                                                int64_t* __restrict__ cache_ids,
                                                uint32_t* __restrict__ cache_slots,
-                                               uint32_t* __restrict__ flags,
+                                               uint32_t* __restrict__ blk_miss,
                                                uint32_t* __restrict__ zero8) {
+  __shared__ uint32_t s_miss;
+  if (threadIdx.x == 0) s_miss = 0;
   if (blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;  // counters of the prepared queues
+  __syncthreads();
   const int sub = lane_sub(), gshift = lane_gshift();
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
   uint32_t missed = 0;
@@ -405,10 +416,10 @@ __global__ void __launch_bounds__(256) k_probe(TableDev t, const int64_t* __rest
       missed += my_slot == kNoSlot;
     }
   }
-  const unsigned long long any = __ballot(missed != 0);
-  if (any) {  // rare: one atomic per lane that saw a miss
-    if (missed) atomicAdd(&flags[0], missed);
-  }
+  // ids not found: summed per workgroup (LDS), one plain store each; k_verify adds them up
+  if (missed) atomicAdd(&s_miss, missed);
+  __syncthreads();
+  if (threadIdx.x == 0) blk_miss[blockIdx.x] = s_miss;
 }
 
 // out[i, :] = row of slot[i] (zeros for kNoSlot). LPR lanes move one row, 16 bytes per lane and
@@ -447,12 +458,26 @@ __global__ void __launch_bounds__(256) k_gather_rows1(TableDev t, const uint32_t
   }
 }
 
-// flags[1] += 1 per wave that sees a position whose id is not the one the lookup recorded.
+// flags[1] += 1 per wave that sees a position whose id is not the one the lookup recorded;
+// flags[0] = ids that lookup did not find (sum of k_probe's per-workgroup counts).
 __global__ void __launch_bounds__(256) k_verify(const int64_t* __restrict__ ids,
                                                 const int64_t* __restrict__ cache_ids, int64_t n,
                                                 uint32_t* __restrict__ flags,
-                                                uint32_t* __restrict__ handout) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *handout = 0;  // k_apply_long's queue cursor
+                                                uint32_t* __restrict__ handout,
+                                                const uint32_t* __restrict__ blk_miss, int n_blk) {
+  __shared__ uint32_t s_sum;
+  if (blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+      *handout = 0;  // k_apply_long's queue cursor
+      s_sum = 0;
+    }
+    __syncthreads();
+    uint32_t m = 0;
+    for (int i = threadIdx.x; i < n_blk; i += blockDim.x) m += blk_miss[i];
+    if (m) atomicAdd(&s_sum, m);
+    __syncthreads();
+    if (threadIdx.x == 0) flags[0] = s_sum;
+  }
   bool bad = false;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x)
@@ -2118,8 +2143,11 @@ static int prep_setup(Table* t) {
   MONO_HIP(hipEventCreateWithFlags(&p.ev_probe, hipEventDisableTiming));
   MONO_HIP(hipEventCreateWithFlags(&p.ev_ready, hipEventDisableTiming));
   MONO_HIP(hipEventCreateWithFlags(&p.ev_verify, hipEventDisableTiming));
+  MONO_HIP(hipEventCreateWithFlags(&p.ev_gated, hipEventDisableTiming));
   MONO_HIP(hipMalloc((void**)&p.d_flags, 256));
   MONO_HIP(hipMemset(p.d_flags, 0, 256));
+  MONO_HIP(hipMalloc((void**)&p.d_blk_miss, kProbeMaxBlocks * sizeof(uint32_t)));
+  MONO_HIP(hipMemset(p.d_blk_miss, 0, kProbeMaxBlocks * sizeof(uint32_t)));
   MONO_HIP(hipHostMalloc((void**)&p.h_flags, 64, hipHostMallocDefault));
   p.h_flags[0] = p.h_flags[1] = 0;
   return 0;
@@ -2131,8 +2159,10 @@ static void prep_destroy(Table* t) {
   if (p.ev_probe) (void)hipEventDestroy(p.ev_probe);
   if (p.ev_ready) (void)hipEventDestroy(p.ev_ready);
   if (p.ev_verify) (void)hipEventDestroy(p.ev_verify);
+  if (p.ev_gated) (void)hipEventDestroy(p.ev_gated);
   if (p.stream) (void)hipStreamDestroy(p.stream);
   if (p.d_flags) (void)hipFree(p.d_flags);
+  if (p.d_blk_miss) (void)hipFree(p.d_blk_miss);
   if (p.h_flags) (void)hipHostFree(p.h_flags);
   p.ws.release();
   p = Table::Prep{};
@@ -2163,8 +2193,9 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
   void* tmp = p.sidx + n_al;
   p.q_base = (char*)tmp + tmp_bytes;
   double hp = host_prof_on() ? host_now() : 0.0;
-  hipLaunchKernelGGL(k_probe, dim3(grid_for(n, 32 * kIlpP)), dim3(256), 0, st, t->d, ids, n,
-                     t->cache_ids, t->cache_slots, p.d_flags, (uint32_t*)p.q_base);
+  p.probe_blocks = grid_for(n, 32 * kIlpP, kProbeMaxBlocks);
+  hipLaunchKernelGGL(k_probe, dim3(p.probe_blocks), dim3(256), 0, st, t->d, ids, n, t->cache_ids,
+                     t->cache_slots, p.d_blk_miss, (uint32_t*)p.q_base);
   MONO_HIP(hipGetLastError());
   host_tick("lookup: launch probe", &hp);
   MONO_HIP(hipEventRecord(p.ev_probe, st));
@@ -2246,8 +2277,10 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
 // The write call's side: use the prepared order if it provably serves this call.
 static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t n, int mode,
                         const float* lrs, int n_lrs, int64_t req_time, hipStream_t st,
-                        int64_t global_step, bool* tried, bool* used) {
+                        int64_t global_step, bool* tried, bool* used, bool allow_missing = false,
+                        int64_t* n_missing = nullptr) {
   *tried = *used = false;
+  if (n_missing) *n_missing = 0;
   Table::Prep& p = t->prep;
   if (p.n == 0 || p.n != n || t->cache_n != n || mode == MODE_IMPORT) return 0;
   *tried = true;
@@ -2255,25 +2288,25 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   // device side: every id was found by the lookup, and the ids are still the same ones
   double hp = host_prof_on() ? host_now() : 0.0;
   hipLaunchKernelGGL(k_verify, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, st, ids, t->cache_ids, n,
-                     p.d_flags, (uint32_t*)p.q_base + 4);
+                     p.d_flags, (uint32_t*)p.q_base + 4, p.d_blk_miss, p.probe_blocks);
   MONO_HIP(hipGetLastError());
   host_tick("update: launch verify", &hp);
   MONO_HIP(hipMemcpyAsync(p.h_flags, p.d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   host_tick("update: memcpy flags", &hp);
   MONO_HIP(hipEventRecord(p.ev_verify, st));
   host_tick("update: record verify", &hp);
-  // the count of ids not found restarts here (k_probe only adds to it): behind the read-back, and
-  // ahead of the wait for the prepared order, where it costs nothing
-  MONO_HIP(hipMemsetAsync(p.d_flags, 0, sizeof(uint32_t), st));
-  host_tick("update: memset flags", &hp);
   MONO_HIP(hipEventSynchronize(p.ev_verify));
   host_tick("update: sync verify (incl. GPU wait)", &hp);
   const bool changed = p.h_flags[1] != p.seen_changed;
   p.seen_changed = p.h_flags[1];
-  if (p.h_flags[0] != 0 || changed) {  // unknown ids to insert, or other ids: full path
-    p.n = 0;  // (and never again from this order: the miss count has just been reset)
+  // other ids, or unknown ids to insert (unless the caller handles those itself: the gated path,
+  // where the prepared order serves the ids the table holds and skips the rest): full path
+  const uint32_t missed = p.h_flags[0];  // of the lookup this order was built by
+  if ((missed != 0 && !allow_missing) || changed) {
+    p.n = 0;
     return 0;
   }
+  if (n_missing) *n_missing = (int64_t)missed;
   // was the prepared order already complete? (see lookup_prepared: the row gather's throttle)
   bool slack = false;
   {
@@ -2319,6 +2352,45 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   MONO_HIP(hipGetLastError());
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
   *used = true;
+  return 0;
+}
+
+// The unknown remainder of a gated write call: `unknown[i]` marks the positions whose id the
+// table does not hold, `pos` = its exclusive scan, U = their number. Compacted in input order,
+// grouped by the 64-bit key, walked by the gated head kernel (filter counts, admission, claims).
+static int gated_unknown(Table* t, const ApplyArgs& a, const int64_t* ids, int64_t n,
+                         const int32_t* unknown, const int32_t* pos, int64_t U, hipStream_t st) {
+  if (U > 0) {
+    const size_t u_al = ((size_t)U + 63) & ~(size_t)63;
+    size_t tmp64 = 0;
+    MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp64, (int64_t*)nullptr, (int64_t*)nullptr,
+                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)U, 0, 64, st));
+    tmp64 = (tmp64 + 255) & ~(size_t)255;
+    const size_t q2 = (queue_bytes(U, t->d.dim) + 255) & ~(size_t)255;
+    // a workspace of its own: the first part's arrays are still being read on the device
+    MONO_TRY(t->ws_gated.ensure(2 * u_al * sizeof(int64_t) + 2 * u_al * sizeof(uint32_t) + tmp64 + q2));
+    int64_t* unk_ids = (int64_t*)t->ws_gated.ptr;
+    int64_t* key_out = unk_ids + u_al;
+    uint32_t* unk_idx = (uint32_t*)(key_out + u_al);
+    uint32_t* idx_out2 = unk_idx + u_al;
+    char* tmp2 = (char*)(idx_out2 + u_al);
+    char* q_base2 = tmp2 + tmp64;
+    hipLaunchKernelGGL(k_compact_unknown, dim3(grid_for(n, 256)), dim3(256), 0, st, ids, unknown, pos, n,
+                       unk_ids, unk_idx);
+    MONO_HIP(hipGetLastError());
+    MONO_HIP(rocprim::radix_sort_pairs(tmp2, tmp64, unk_ids, key_out, unk_idx, idx_out2, (size_t)U, 0,
+                                       64, st));
+    ApplyArgs g = a;
+    g.n = U;
+    g.from_keys = 1;
+    g.skeys = key_out;
+    g.sidx = idx_out2;
+    g.sort_err = nullptr;
+    uint4* heads = nullptr;
+    MONO_TRY(queue_setup(&g, q_base2, U, t->d.dim, &heads, st));
+    MONO_TRY(launch_apply(t, g, heads, g.qcount + 1, st));
+    MONO_HIP(hipGetLastError());
+  }
   return 0;
 }
 
@@ -2378,36 +2450,50 @@ static int write_path_gated(Table* t, void* filter, ApplyArgs a, const int64_t* 
   }
   MONO_HIP(hipEventSynchronize(t->prep.ev_verify));
   const int64_t U = (int64_t)h_last[0] + h_last[1];
+  MONO_TRY(gated_unknown(t, a, ids, n, unknown, pos, U, st));
+  if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
+  return filter_after_batch(filter, st, U);
+}
+
+// The gated write path behind a lookup's prepared order (try_prepared with allow_missing): the
+// ids the table holds have just been applied through the prepared order — the positions the
+// lookup did not find carry kNoSlot there and were skipped — and the U unknown ones are exactly
+// those positions: marked from the slot record, compacted in input order, walked by the gated
+// head kernel. No read-back of its own: U is the lookup's miss count k_verify's read-back brought.
+__global__ void __launch_bounds__(256) k_unknown_from_slots(const uint32_t* __restrict__ slots,
+                                                            int64_t n, int32_t* __restrict__ unknown) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    unknown[i] = slots[i] == kNoSlot ? 1 : 0;
+}
+static int gated_after_prepared(Table* t, void* filter, const ApplyArgs& a, const int64_t* ids,
+                                int64_t n, int64_t U, hipStream_t st) {
   if (U > 0) {
-    const size_t u_al = ((size_t)U + 63) & ~(size_t)63;
-    size_t tmp64 = 0;
-    MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp64, (int64_t*)nullptr, (int64_t*)nullptr,
-                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)U, 0, 64, st));
-    tmp64 = (tmp64 + 255) & ~(size_t)255;
-    const size_t q2 = (queue_bytes(U, t->d.dim) + 255) & ~(size_t)255;
-    // a workspace of its own: the first part's arrays are still being read on the device
-    MONO_TRY(t->ws_gated.ensure(2 * u_al * sizeof(int64_t) + 2 * u_al * sizeof(uint32_t) + tmp64 + q2));
-    int64_t* unk_ids = (int64_t*)t->ws_gated.ptr;
-    int64_t* key_out = unk_ids + u_al;
-    uint32_t* unk_idx = (uint32_t*)(key_out + u_al);
-    uint32_t* idx_out2 = unk_idx + u_al;
-    char* tmp2 = (char*)(idx_out2 + u_al);
-    char* q_base2 = tmp2 + tmp64;
-    hipLaunchKernelGGL(k_compact_unknown, dim3(grid_for(n, 256)), dim3(256), 0, st, ids, unknown, pos, n,
-                       unk_ids, unk_idx);
+    // On the table's own stream, BESIDE the apply kernels of the known ids that try_prepared has
+    // just launched on the caller's: a dozen launch-bound kernels over a few per cent of the batch
+    // (scan, compaction, 64-bit sort, gated walk) that touch other rows, other scratch and the
+    // filter, which the known part never reads. The caller's stream joins before the filter's
+    // end-of-batch step.
+    Table::Prep& p = t->prep;
+    hipStream_t gs = p.stream;
+    MONO_HIP(hipStreamWaitEvent(gs, p.ev_verify, 0));  // (the ids are final, the slot record read)
+    const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
+    size_t scan_tmp = 0;
+    MONO_HIP(rocprim::exclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int32_t*)nullptr, 0,
+                                     (size_t)n, rocprim::plus<int32_t>(), gs));
+    scan_tmp = (scan_tmp + 255) & ~(size_t)255;
+    MONO_TRY(t->ws.ensure(2 * n_al * sizeof(int32_t) + scan_tmp));
+    int32_t* unknown = (int32_t*)t->ws.ptr;
+    int32_t* pos = unknown + n_al;
+    char* scan_buf = (char*)(pos + n_al);
+    hipLaunchKernelGGL(k_unknown_from_slots, dim3(grid_for(n, 1024)), dim3(256), 0, gs, t->cache_slots, n,
+                       unknown);
     MONO_HIP(hipGetLastError());
-    MONO_HIP(rocprim::radix_sort_pairs(tmp2, tmp64, unk_ids, key_out, unk_idx, idx_out2, (size_t)U, 0,
-                                       64, st));
-    ApplyArgs g = a;
-    g.n = U;
-    g.from_keys = 1;
-    g.skeys = key_out;
-    g.sidx = idx_out2;
-    g.sort_err = nullptr;
-    uint4* heads = nullptr;
-    MONO_TRY(queue_setup(&g, q_base2, U, t->d.dim, &heads, st));
-    MONO_TRY(launch_apply(t, g, heads, g.qcount + 1, st));
-    MONO_HIP(hipGetLastError());
+    MONO_HIP(rocprim::exclusive_scan(scan_buf, scan_tmp, unknown, pos, 0, (size_t)n,
+                                     rocprim::plus<int32_t>(), gs));
+    MONO_TRY(gated_unknown(t, a, ids, n, unknown, pos, U, gs));
+    MONO_HIP(hipEventRecord(p.ev_gated, gs));
+    MONO_HIP(hipStreamWaitEvent(st, p.ev_gated, 0));
   }
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
   return filter_after_batch(filter, st, U);
@@ -2427,20 +2513,24 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   // "one lookup, then an update of as many ids" is what makes the next lookup prepare the update
   // order; two prepared orders in a row that could not be used (other ids, ids to insert) switch
   // it off again for a while
-  const bool pattern = !from_keys && mode != MODE_IMPORT && t->cache_n == n &&
-                       t->lookups_since_update == 1;
+  const bool pattern = mode != MODE_IMPORT && t->cache_n == n && t->lookups_since_update == 1;
   t->lookups_since_update = 0;
-  if (!from_keys && mode != MODE_IMPORT) t->last_mode_class = mode_class(mode);
+  if (mode != MODE_IMPORT) t->last_mode_class = mode_class(mode);
   bool tried = false, prepared = false;
-  if (!from_keys)
+  int64_t missing = 0;
+  // With a filter the prepared order serves the ids the table holds and the unknown ones are
+  // gated afterwards; those may be inserted, so the order is only used while the table cannot
+  // need a rehash for this batch (a rehash moves every row the order points at).
+  const bool room = !from_keys || t->used_upper + n <= (int64_t)(kMaxLoad * (double)t->d.cap);
+  if (room)
     MONO_TRY(try_prepared(t, ids, src, n, mode, lrs, n_lrs, req_time, st, global_step, &tried,
-                          &prepared));
+                          &prepared, /*allow_missing=*/from_keys, &missing));
   if (prepared) t->prep_strikes = 0;
   else if (tried) ++t->prep_strikes;
   if (++t->updates_since_strike >= 64) t->updates_since_strike = t->prep_strikes = 0;
   t->expect_update = pattern && t->prep_strikes < 2;
-  if (prepared) return 0;
-  MONO_TRY(ensure_room(t, n, st));
+  if (prepared && !from_keys) return 0;
+  if (!prepared) MONO_TRY(ensure_room(t, n, st));
 
   ApplyArgs a{};
   a.skip_slot = kNoSlot;
@@ -2455,6 +2545,10 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   a.global_step = global_step;
   a.sort_err = from_keys ? nullptr : sort_error_word();
   for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
+  if (prepared) {  // (from_keys) the known ids are applied; the lookup's misses remain
+    t->used_upper += missing;
+    return gated_after_prepared(t, filter, a, ids, n, missing, st);
+  }
 
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
   const size_t q_bytes = queue_bytes(n, t->d.dim);
