@@ -129,9 +129,9 @@ struct Table {
     bool gather_full = false;
     int slack_run = 0, full_backoff = 0, full_backoff_len = 64;
     // [0] ids the lookup did not find  [1] positions k_verify found changed (running count).
-    // [0] is WRITTEN by k_verify: the sum of the per-workgroup miss counts the last k_probe left in
-    // d_blk_miss (plain stores, no atomics: with a hash filter 5 % of a batch misses, and 85 k
-    // atomics on one word made k_probe 198 us instead of 42) — exactly that lookup's count,
+    // [0] is zeroed by every k_probe and filled by k_verify from the per-workgroup miss counts that
+    // k_probe left in d_blk_miss (plain stores: with a hash filter 5 % of a batch misses, and 85 k
+    // atomics on one word made k_probe 198 us instead of 42) — exactly the last lookup's count,
     // whatever happened to the lookups before it.
     uint32_t* d_flags = nullptr;
     uint32_t* d_blk_miss = nullptr;  // [kProbeMaxBlocks]
@@ -383,10 +383,12 @@ __global__ void __launch_bounds__(256) k_probe(TableDev t, const int64_t* __rest
                                                int64_t* __restrict__ cache_ids,
                                                uint32_t* __restrict__ cache_slots,
                                                uint32_t* __restrict__ blk_miss,
-                                               uint32_t* __restrict__ zero8) {
+                                               uint32_t* __restrict__ zero8,
+                                               uint32_t* __restrict__ miss_total) {
   __shared__ uint32_t s_miss;
   if (threadIdx.x == 0) s_miss = 0;
   if (blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;  // counters of the prepared queues
+  if (blockIdx.x == 0 && threadIdx.x == 8) *miss_total = 0;        // k_verify adds this lookup's up
   __syncthreads();
   const int sub = lane_sub(), gshift = lane_gshift();
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
@@ -465,18 +467,12 @@ __global__ void __launch_bounds__(256) k_verify(const int64_t* __restrict__ ids,
                                                 uint32_t* __restrict__ flags,
                                                 uint32_t* __restrict__ handout,
                                                 const uint32_t* __restrict__ blk_miss, int n_blk) {
-  __shared__ uint32_t s_sum;
-  if (blockIdx.x == 0) {
-    if (threadIdx.x == 0) {
-      *handout = 0;  // k_apply_long's queue cursor
-      s_sum = 0;
-    }
-    __syncthreads();
-    uint32_t m = 0;
-    for (int i = threadIdx.x; i < n_blk; i += blockDim.x) m += blk_miss[i];
-    if (m) atomicAdd(&s_sum, m);
-    __syncthreads();
-    if (threadIdx.x == 0) flags[0] = s_sum;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *handout = 0;  // k_apply_long's queue cursor
+  if (threadIdx.x == 0) {  // this workgroup's slice of k_probe's per-workgroup miss counts
+    const int per = (n_blk + (int)gridDim.x - 1) / (int)gridDim.x;
+    uint32_t mc = 0;
+    for (int i = blockIdx.x * per; i < min(n_blk, ((int)blockIdx.x + 1) * per); ++i) mc += blk_miss[i];
+    if (mc) atomicAdd(&flags[0], mc);  // (no atomic at all when every id was found)
   }
   bool bad = false;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -2195,7 +2191,7 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
   double hp = host_prof_on() ? host_now() : 0.0;
   p.probe_blocks = grid_for(n, 32 * kIlpP, kProbeMaxBlocks);
   hipLaunchKernelGGL(k_probe, dim3(p.probe_blocks), dim3(256), 0, st, t->d, ids, n, t->cache_ids,
-                     t->cache_slots, p.d_blk_miss, (uint32_t*)p.q_base);
+                     t->cache_slots, p.d_blk_miss, (uint32_t*)p.q_base, p.d_flags);
   MONO_HIP(hipGetLastError());
   host_tick("lookup: launch probe", &hp);
   MONO_HIP(hipEventRecord(p.ev_probe, st));
@@ -2546,6 +2542,9 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   a.sort_err = from_keys ? nullptr : sort_error_word();
   for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
   if (prepared) {  // (from_keys) the known ids are applied; the lookup's misses remain
+    // (this order is used up: a second update on it would add the miss counts to flags[0] again,
+    // and the unknown ids are being inserted now)
+    t->prep.n = 0;
     t->used_upper += missing;
     return gated_after_prepared(t, filter, a, ids, n, missing, st);
   }
