@@ -1370,18 +1370,21 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
 // row-major LDS tile in input order, eight LDS reads in flight — bit-exact with the sequential
 // reference, one dependent floating-point add per row.
 constexpr int kLoaders = 192;
-constexpr int kLTileFloats = 6144;             // 24 KB per LDS tile
-constexpr int kLStage4 = kLTileFloats / 4 / kLoaders;  // 8 float4 per loader thread per tile
+constexpr int kLTileFloatsDefault = 6144;      // 24 KB per LDS tile, 8 float4 per loader thread
 constexpr int kLMaxRows = 2 * kLoaders;        // rows per tile (two prefetched indices per thread)
 constexpr int kLIdxRing = 8;
 
-// OCC: workgroups per CU the register budget is set for. Two for the layout gradient's sums (it
-// runs hundreds of thousands of rows through these chains at dim 16 and nothing else competes for
-// the CUs' registers); one beside the table's k_apply and for the exchange's gradient sum, where
+// OCC: workgroups per CU the register budget is set for, TILE: floats per LDS tile. Four workgroups
+// with half-size tiles (36 KB of LDS each) for the layout gradient's sums (it runs millions of rows
+// through these chains — one in-order chain per workgroup — and nothing else competes for the CUs'
+// registers); one beside the table's k_apply and for the exchange's gradient sum, where
 // the second workgroup costs the kernel that carries the traffic more than it gains (config 2:
 // 355 -> 396 us per step, config 4: 1.07 -> 1.12 ms).
-template <int OPTK, int MODE, int OCC = 1>
+template <int OPTK, int MODE, int OCC = 1, int TILE = kLTileFloatsDefault>
 __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a) {
+  constexpr int kLTileFloats = TILE;                     // floats per LDS tile
+  constexpr int kLStage4 = kLTileFloats / 4 / kLoaders;  // float4 per loader thread per tile
+  static_assert(kLStage4 * 4 * kLoaders == kLTileFloats, "tile size must be a multiple of 4 * kLoaders");
   __shared__ __attribute__((aligned(16))) float tile[2][kLTileFloats];
   __shared__ uint32_t idxs[kLIdxRing][kLMaxRows];
   __shared__ uint32_t s_qi;
@@ -1912,7 +1915,7 @@ static void launch_long_m(const Table* t, const ApplyArgs& a, unsigned grid, hip
       break;
     case MODE_SET_SUM:
       if (a.src_tab || a.src_ptrs)
-        hipLaunchKernelGGL((k_apply_long<OPTK, MODE_SET_SUM, 2>), dim3(grid), dim3(256), 0, st, t->d, a);
+        hipLaunchKernelGGL((k_apply_long<OPTK, MODE_SET_SUM, 4, 3072>), dim3(grid), dim3(256), 0, st, t->d, a);
       else
         hipLaunchKernelGGL((k_apply_long<OPTK, MODE_SET_SUM>), dim3(grid), dim3(256), 0, st, t->d, a);
       break;
