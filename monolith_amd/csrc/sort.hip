@@ -241,7 +241,11 @@ __global__ void __launch_bounds__(kSortThreads) k_sort_scatter(
 // Tile numbers are handed out by an atomic ticket, so every tile a workgroup waits for has
 // already started and publishes before it waits on anything: the wait always ends. The spin is
 // bounded all the same; a time-out raises err[0] (mono_sort_error) instead of hanging the GPU.
-constexpr int kFusedMaxTiles = 1024;  // 8.4 M pairs (config 3's layout gradient sorts 6.5 M)
+constexpr int kFusedMaxTiles = 1024;  // 8.4 M pairs
+// Beyond this many tiles the three plain kernels of a pass are cheaper than the fused one (800
+// tiles, config 3's 6.5 M uses: 8 + 10 + 44 us against 64-82 us — the look-back chain grows with
+// the tile count, the plain scatter does not).
+constexpr int kFusedPreferTiles = 512;
 constexpr int kFusedMaxPasses = 4;
 constexpr uint32_t kSpinLimit = 1u << 22;
 constexpr uint32_t kRowReady = 0x80000000u;  // a tile holds at most 8192 elements
@@ -509,7 +513,7 @@ int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uin
   p += (((size_t)tiles * kSortMaxDigits * sizeof(uint32_t)) + 255) & ~(size_t)255;
   uint32_t* tk = (uint32_t*)p;
   uint32_t* tv = tk + n_al;
-  if (fused_enabled() && passes >= 2 && tiles <= kFusedMaxTiles && passes <= kFusedMaxPasses) {
+  if (fused_enabled() && passes >= 2 && tiles <= kFusedPreferTiles && passes <= kFusedMaxPasses) {
     uint32_t* const g_sort_err = sort_error_word();
     MONO_REQUIRE(g_sort_err, "sort_pairs_u32: cannot resolve the error word of this device");
     char* q = (char*)(tv + n_al);

@@ -1232,6 +1232,22 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       float acc[V];
       vload<V>(acc, src_row<kPtrs>(a, first == j ? idx0 : a.sidx[first], D) + e0);
       int64_t p = first + 1;
+      // the stateless sums (layout gradient) meet tens of thousands of 10..96-row segments per
+      // batch: eight rows in flight, their occurrence values fetched by one coalesced load of the
+      // sub-group (lane u holds value u) instead of one dependent load each. (V = 4 would spill
+      // at 8 waves / SIMD; the shuffle needs all 8 lanes inside this column loop.)
+      if (MODE_T == MODE_SET_SUM && V <= 2 && D % (8 * V) == 0) {
+        for (; p + 8 <= end; p += 8) {
+          const uint32_t mine = a.sidx[p + sub];
+          float g[8][V];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) vload<V>(g[u], src_row<kPtrs>(a, __shfl(mine, u, 8), D) + e0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] = acc[q] + g[u][q];
+        }
+      }
       for (; p + 4 <= end; p += 4) {  // 4 independent loads in flight, adds stay in order
         float g0[V], g1[V], g2[V], g3[V];
         vload<V>(g0, src_row<kPtrs>(a, a.sidx[p], D) + e0);
