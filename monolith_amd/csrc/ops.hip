@@ -362,6 +362,7 @@ struct SlotMeta {  // per merged slot, device array
   int64_t hash_base;  // first cell of this slot's dedup region
   uint64_t hash_mask; // region size - 1 (power of two); cell [hash_base + size] = key -1
   int32_t dim;
+  int64_t head_base;  // first index of this slot's head (its first 1/64) among all slots' heads
 };
 
 __device__ inline int find_slot_of(const SlotMeta* sm, int M, int64_t gidx) {
@@ -384,43 +385,60 @@ __device__ inline int64_t floormod_dev(int64_t a, int64_t b) {
 // records the occurrence, so a key seen once costs one atomic (with {key, first} cells it cost a
 // 64-bit CAS plus an atomicMin, and device-scope atomics on random words are the bound here,
 // ~20 G/s); the set is a quarter of the size, and so is the fill that resets it.
+__device__ __forceinline__ void reorder_insert_one(const SlotMeta& sl, int64_t g, uint32_t* hfirst,
+                                                   uint32_t* hcell) {
+  const int64_t s_base = sl.base, s_hash_base = sl.hash_base;
+  const uint64_t s_mask = sl.hash_mask;
+  const int64_t* __restrict__ s_ids = sl.ids;
+  const int64_t key = s_ids[g - s_base];
+  uint64_t p = mix64((uint64_t)key) & s_mask;
+  for (;;) {
+    uint32_t* cp = hfirst + (s_hash_base + (int64_t)p);
+    uint32_t cur = *cp;
+    if (cur == 0xFFFFFFFFu) {
+      cur = atomicCAS(cp, 0xFFFFFFFFu, (uint32_t)g);
+      if (cur == 0xFFFFFFFFu) break;  // claimed: the cell says "first seen at g"
+    }
+    // the cell belongs to the key of occurrence `cur` (same slot: regions are per slot); a
+    // later atomicMin can only replace cur by another occurrence of that same key
+    if (s_ids[(int64_t)cur - s_base] == key) {
+      // first only decreases: an occurrence that already sees a smaller index has nothing to
+      // add, which spares the hot keys tens of thousands of serialised atomics on one word. A
+      // stale value can only be LARGER than the current one, i.e. cause a redundant atomic.
+      if (cur > (uint32_t)g) atomicMin(cp, (uint32_t)g);
+      break;
+    }
+    p = (p + 1) & s_mask;
+  }
+  hcell[g] = (uint32_t)(s_hash_base + (int64_t)p);
+}
+
 __global__ void __launch_bounds__(256) k_reorder_insert(ReorderArgs a, const SlotMeta* sm,
                                                         uint32_t* hfirst, uint32_t* hcell,
-                                                        int phase) {
+                                                        int phase, int64_t heads_total) {
   // Two launches. Phase 0 inserts only the first 1/64 of every slot's occurrences, phase 1 the
   // rest. A hot key (thousands of occurrences) almost surely occurs in that head, so by the time
-  // the bulk runs its cell already holds a small index and the guarded atomicMin below is
-  // skipped; in one launch ~10 k concurrent occurrences of one key would all see a large index
-  // and serialise on a single word (~90 atomics / us).
+  // the bulk runs its cell already holds a small index and the guarded atomicMin is skipped; in
+  // one launch ~10 k concurrent occurrences of one key would all see a large index and
+  // serialise on a single word (~90 atomics / us). Phase 0 walks the heads only (packed by
+  // SlotMeta::head_base) instead of skipping 63 of every 64 occurrences.
+  if (phase == 0) {
+    for (int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; h < heads_total;
+         h += (int64_t)gridDim.x * blockDim.x) {
+      int lo = 0, hi = a.M - 1;
+      while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (sm[mid].head_base <= h) lo = mid; else hi = mid - 1;
+      }
+      reorder_insert_one(sm[lo], sm[lo].base + (h - sm[lo].head_base), hfirst, hcell);
+    }
+    return;
+  }
   for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < a.total;
        g += (int64_t)gridDim.x * blockDim.x) {
     const int m = find_slot_of(sm, a.M, g);
-    const int64_t s_base = sm[m].base, s_len = sm[m].len, s_hash_base = sm[m].hash_base;
-    const uint64_t s_mask = sm[m].hash_mask;
-    const int64_t* __restrict__ s_ids = sm[m].ids;
-    const bool head = (g - s_base) < ((s_len + 63) >> 6);
-    if (head != (phase == 0)) continue;
-    const int64_t key = s_ids[g - s_base];
-    uint64_t p = mix64((uint64_t)key) & s_mask;
-    for (;;) {
-      uint32_t* cp = hfirst + (s_hash_base + (int64_t)p);
-      uint32_t cur = *cp;
-      if (cur == 0xFFFFFFFFu) {
-        cur = atomicCAS(cp, 0xFFFFFFFFu, (uint32_t)g);
-        if (cur == 0xFFFFFFFFu) break;  // claimed: the cell says "first seen at g"
-      }
-      // the cell belongs to the key of occurrence `cur` (same slot: regions are per slot); a
-      // later atomicMin can only replace cur by another occurrence of that same key
-      if (s_ids[(int64_t)cur - s_base] == key) {
-        // first only decreases: an occurrence that already sees a smaller index has nothing to
-        // add, which spares the hot keys tens of thousands of serialised atomics on one word. A
-        // stale value can only be LARGER than the current one, i.e. cause a redundant atomic.
-        if (cur > (uint32_t)g) atomicMin(cp, (uint32_t)g);
-        break;
-      }
-      p = (p + 1) & s_mask;
-    }
-    hcell[g] = (uint32_t)(s_hash_base + (int64_t)p);
+    if ((g - sm[m].base) < ((sm[m].len + 63) >> 6)) continue;  // a head: phase 0 took it
+    reorder_insert_one(sm[m], g, hfirst, hcell);
   }
 }
 
@@ -926,7 +944,7 @@ static int reorder_begin(const int64_t* const* inputs, const int64_t* h_lens, in
   g_reorder.pin = nullptr;
   g_last_plan_token = 0;
   std::vector<SlotMeta> sm(M);
-  int64_t total = 0, cells = 0;
+  int64_t total = 0, cells = 0, heads_total = 0;
   for (int m = 0; m < M; ++m) {
     uint64_t sz = 8;
     while (sz < (uint64_t)h_lens[m] * 2) sz <<= 1;
@@ -937,6 +955,8 @@ static int reorder_begin(const int64_t* const* inputs, const int64_t* h_lens, in
     sm[m].hash_base = cells;
     sm[m].hash_mask = sz - 1;
     sm[m].dim = h_dims[m];
+    sm[m].head_base = heads_total;
+    heads_total += (h_lens[m] + 63) >> 6;
     total += h_lens[m];
     cells += (int64_t)sz + 1;
   }
@@ -979,8 +999,9 @@ static int reorder_begin(const int64_t* const* inputs, const int64_t* h_lens, in
   ReorderArgs a{M, N, shard_rule, total};
   const dim3 grid(grid_for(total, 256)), blk(256);
   double hp = host_prof_on() ? host_now() : 0.0;
-  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hfirst, hcell, 0);
-  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hfirst, hcell, 1);
+  hipLaunchKernelGGL(k_reorder_insert, dim3(grid_for(heads_total, 256)), blk, 0, st, a, d_sm, hfirst, hcell,
+                     0, heads_total);
+  hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, a, d_sm, hfirst, hcell, 1, (int64_t)0);
   hipLaunchKernelGGL(k_reorder_keys, grid, blk, 0, st, a, d_sm, hfirst, hcell, skey, sidx);
   MONO_HIP(hipGetLastError());
   MONO_TRY(sort_pairs(skey, skey2, sidx, sidx2, (size_t)total, bits_for_u((uint64_t)N * M), st,
@@ -1091,7 +1112,7 @@ int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* 
   for (int i = 0; i < n_out; ++i) h_out_counts[i] = 0;
   std::vector<SlotMeta> sm(M);
   std::vector<RunMeta> rm(M);
-  int64_t total = 0, cells = 0, total_runs = 0;
+  int64_t total = 0, cells = 0, total_runs = 0, heads_total = 0;
   for (int m = 0; m < M; ++m) {
     MONO_REQUIRE(h_lens[m] >= 0 && h_runs[m] >= 0, "mono_sharding_sparse_fids: negative length");
     MONO_REQUIRE(h_lens[m] == 0 || fids[m], "mono_sharding_sparse_fids: null fids[%d]", m);
@@ -1099,7 +1120,8 @@ int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* 
     MONO_REQUIRE(h_runs[m] > 0 || h_lens[m] == 0, "mono_sharding_sparse_fids: fids without runs");
     uint64_t sz = 8;
     while (sz < (uint64_t)h_lens[m] * 2) sz <<= 1;
-    sm[m] = SlotMeta{fids[m], nullptr, total, h_lens[m], cells, sz - 1, 1};
+    sm[m] = SlotMeta{fids[m], nullptr, total, h_lens[m], cells, sz - 1, 1, heads_total};
+    heads_total += (h_lens[m] + 63) >> 6;
     rm[m] = RunMeta{row_splits[m], total, total_runs, h_runs[m]};
     total += h_lens[m];
     total_runs += h_runs[m];
@@ -1152,8 +1174,9 @@ int mono_sharding_sparse_fids(const int64_t* const* fids, const int64_t* const* 
   if (unique) {
     MONO_HIP(hipMemsetAsync(hfirst, 0xFF, c_al * 4, st));
     ReorderArgs ra{M, ps_num, 0, total};
-    hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hfirst, hcell, 0);
-    hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hfirst, hcell, 1);
+    hipLaunchKernelGGL(k_reorder_insert, dim3(grid_for(heads_total, 256)), blk, 0, st, ra, d_sm, hfirst,
+                       hcell, 0, heads_total);
+    hipLaunchKernelGGL(k_reorder_insert, grid, blk, 0, st, ra, d_sm, hfirst, hcell, 1, (int64_t)0);
   }
   hipLaunchKernelGGL(k_shard_keys, grid, blk, 0, st, a, d_sm, hfirst, hcell, skey);
   MONO_HIP(hipGetLastError());
