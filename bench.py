@@ -590,6 +590,10 @@ def main():
                   help="config 3: the fused lookup + pool in the step instead of lookup + "
                        "fused_embedding_to_layout (1.98 against 1.95 ms: the update order prepared "
                        "beside the pooling kernel slows it by what the fusion saves)")
+  ap.add_argument("--no-hint", action="store_true",
+                  help="config 2: do not announce the next batch's ids (mono_table_lookup_hint) "
+                       "between a step's lookup and its update")
+  ap.add_argument("--hint-ahead", type=int, default=2, help="config 2: lookups announced ahead (1..3)")
   ap.add_argument("--config", type=int, default=0, help="2 | 3 | 4 | 5 (default: 2, or 4 when N > 1)")
   ap.add_argument("--dim", type=int, default=0, help="config 4 / --sharded: row width (default 64 / 16)")
   args = ap.parse_args()
@@ -657,6 +661,12 @@ def main():
   def step(i):
     ids = pool[i % n_pool]
     _lib.check(_lib.lib.mono_table_lookup(h, _lib.vp(ids), C.c_int64(n), _lib.vp(out), sp))
+    if not args.no_hint:
+      # the input pipeline knows the next batch while this one trains (the reference prefetches
+      # batches the same way): its slots and update order are resolved beside this step's update
+      for ahead in range(1, args.hint_ahead + 1):  # (the table takes the one that extends its queue)
+        _lib.check(_lib.lib.mono_table_lookup_hint(h, _lib.vp(pool[(i + ahead) % n_pool]),
+                                                   C.c_int64(n), C.c_int(ahead), sp))
     _lib.check(_lib.lib.mono_table_apply_gradients(h, None, _lib.vp(ids), _lib.vp(grad),
                                                    C.c_int64(n), lrs, C.c_int(1), C.c_int64(10 + i),
                                                    C.c_int64(i), C.c_int(1), sp))
@@ -762,8 +772,10 @@ def main():
       "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
       "vs_baseline": None, "dtype": "f32", "data": "synthetic",
       "config": {"workload": "criteo-shaped: 26 single-hot slots, %.3g-row table, dim 16 fp32, "
-                             "batch %d, Adagrad, lookup + apply_gradients(dedup)" %
-                             (total_rows, args.batch),
+                             "batch %d, Adagrad, lookup + apply_gradients(dedup)%s" %
+                             (total_rows, args.batch,
+                              "" if args.no_hint else ", the next two batches' ids announced by "
+                              "lookup_hint"),
                  "fids_per_step": n, "unique_ratio": uniq, "skew": args.skew,
                  "parallelism": "independent table per GPU" if world > 1 else "1 GPU",
                  "populate_s": t_pop, "table_rows": rows_live},

@@ -156,6 +156,24 @@ int mono_table_slice_size(void* table);  /* ::slice_size = number of segments */
 
 /* ops/hash_table_lookup_op.cc:36-73 (MonolithHashTableLookup): out[n, dim]; miss => zeros. */
 int mono_table_lookup(void* table, const int64_t* ids, int64_t n, float* out, void* stream);
+/* No counterpart in the reference's single-table op set: it is what the reference's input pipeline
+ * does one level up, where the next batch's ids are known while the current step is still running
+ * (embedding_prefetch_capacity / enable_async_optimize in distributed_ps_sync.py, the data
+ * pipeline's prefetch in native_task.py) — here without the staleness those options accept.
+ * `ids` (device, ready on `stream`) are the ids of the mono_table_lookup `ahead` calls from now on
+ * this table: 1 = the next lookup, 2 = the one after it, at most 3. They are read on another
+ * stream some time after the call and must stay valid until the lookup they announce has been
+ * issued (unlike every other argument of this library, which only has to be valid in stream order). In a training loop (lookup, update, lookup, ...) the table
+ * resolves their slots and prepares the update order on streams of its own, beside the updates
+ * of the batches before; the lookup they were announced for checks on the device that it got the
+ * hinted ids and only gathers the rows. Purely an optimisation: results are the same with or
+ * without the call, whatever ids follow (a hint that does not match, or that a key insertion /
+ * eviction / clear has overtaken, is dropped). The table keeps a queue, oldest first, and takes a
+ * hint only if it extends that queue by one (`ahead` == hints queued + 1): a caller may announce
+ * ahead = 1 and ahead = 2 at every step, between the lookup and its update, and the table picks
+ * what it does not have yet. Two ahead is what pays: beside an update the sort runs
+ * several times slower than alone and needs the whole step. A no-op outside the training pattern. */
+int mono_table_lookup_hint(void* table, const int64_t* ids, int64_t n, int ahead, void* stream);
 
 /* ops/hash_table_update_op.cc:28-50 (MonolithHashTableAssign), bridge :156-184. filter may be NULL. */
 int mono_table_assign(void* table, void* filter, const int64_t* ids, const float* values,

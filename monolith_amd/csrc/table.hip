@@ -140,7 +140,33 @@ struct Table {
     uint32_t seen_changed = 0;    // d_flags[1] as of the last read-back (it only grows)
     bool chain_pending = false;   // a sort + classify chain was launched and the caller's stream
                                   // has not waited for it since
+    bool hinted = false;          // built by mono_table_lookup_hint: valid only if d_flags[2] == 0
   } prep;
+  // mono_table_lookup_hint: the slots and the update order of the NEXT lookups' ids (a queue of up
+  // to kHintDepth, oldest first), resolved ahead on the table's chain streams while the current
+  // steps are still running (an update through the prepared order never changes the key set, so
+  // the probe does not have to wait for it). Beside an update the latency-bound sort runs several
+  // times slower than alone, which is why a hint one lookup ahead is not enough: two ahead gives
+  // the chain a whole step. The lookup that follows swaps the oldest hint into `prep` (and the
+  // hinted slot record into cache_*), checks on the device that its ids are the hinted ones
+  // (k_hint_fix re-probes any that are not and counts them: the order is then not used, and the
+  // queue is dropped) and only gathers the rows. Every call that may change the key set drops the
+  // queue.
+  static constexpr int kHintDepth = 3;
+  struct Hint {
+    Prep p;
+    int64_t* ids = nullptr;
+    uint32_t* slots = nullptr;
+    int64_t cap = 0;
+  } hints[kHintDepth];
+  int hint_head = 0, hint_count = 0;
+  // the streams the update-order chains run on (all Preps share them, alternating: the process
+  // has four hardware queues, and the caller's stream and the apply stream take two)
+  hipStream_t chain_stream[2] = {nullptr, nullptr};
+  int preps_made = 0;
+  hipEvent_t ev_hint_src = nullptr;  // the caller's stream at the time of the hint (its ids are ready)
+  hipEvent_t ev_keys = nullptr;      // behind the last call that may have changed the key set
+  bool ev_keys_set = false;
   bool expect_update = false;     // the last update came right after one lookup of as many ids
   int lookups_since_update = 0;
   int prep_strikes = 0;           // prepared orders in a row that the update could not use
@@ -388,7 +414,8 @@ __global__ void __launch_bounds__(256) k_probe(TableDev t, const int64_t* __rest
   __shared__ uint32_t s_miss;
   if (threadIdx.x == 0) s_miss = 0;
   if (blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;  // counters of the prepared queues
-  if (blockIdx.x == 0 && threadIdx.x == 8) *miss_total = 0;        // k_verify adds this lookup's up
+  if (blockIdx.x == 0 && threadIdx.x == 8) miss_total[0] = 0;      // k_verify adds this lookup's up
+  if (blockIdx.x == 0 && threadIdx.x == 9) miss_total[2] = 0;      // ids that were not the hinted ones
   __syncthreads();
   const int sub = lane_sub(), gshift = lane_gshift();
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
@@ -480,6 +507,35 @@ __global__ void __launch_bounds__(256) k_verify(const int64_t* __restrict__ ids,
     bad = bad || ids[i] != cache_ids[i];
   const unsigned long long m = __ballot(bad);
   if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&flags[1], 1u);
+}
+
+// A lookup that consumes a hint: positions whose id is not the hinted one are resolved now and
+// the record corrected (so the rows gathered next are the right ones whatever was hinted);
+// flags[2] counts them, and the hinted update order is only used when there were none.
+__global__ void __launch_bounds__(256) k_hint_fix(TableDev t, const int64_t* __restrict__ ids, int64_t n,
+                                                  int64_t* __restrict__ rec_ids,
+                                                  uint32_t* __restrict__ rec_slots,
+                                                  uint32_t* __restrict__ flags) {
+  const int sub = lane_sub(), gshift = lane_gshift();
+  const int lane = threadIdx.x & 63;
+  for (int64_t i0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; i0 < n;
+       i0 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i0 + lane;
+    const bool bad = i < n && ids[i] != rec_ids[i];
+    unsigned long long m = __ballot(bad);
+    if (m && lane == __ffsll((long long)m) - 1) atomicAdd(&flags[2], (uint32_t)__popcll(m));
+    while (m) {  // rare: one sub-group probe per mismatching position
+      const int l = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int64_t key = __shfl(i < n ? ids[i] : kEmpty, l);
+      // (every 8-lane group probes the same key; group 0's answer is kept)
+      const uint32_t sl = group_find(t, key, sub, gshift);
+      if (lane == 0) {
+        rec_ids[i0 + l] = key;
+        rec_slots[i0 + l] = sl;
+      }
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) k_contains(TableDev t, const int64_t* __restrict__ ids,
@@ -1829,10 +1885,14 @@ static int read_counters(Table* t, hipStream_t st, int64_t* live, int64_t* tombs
   return sort_error_report(h_err);  // every host read-back of the write path reports a failed sort
 }
 
+static int hint_drop(Table* t, hipStream_t st);
+static int keys_changed(Table* t, hipStream_t st);
+
 // Rehash into a table of `new_cap` slots (drops tombstones). Peak memory = old + new arrays.
 static int rehash(Table* t, uint64_t new_cap, hipStream_t st) {
   t->cache_n = 0;  // every key moves
   t->prep.n = 0;
+  MONO_TRY(hint_drop(t, st));
   TableDev nw = t->d;
   nw.keys = nullptr; nw.ts = nullptr; nw.rows = nullptr; nw.special = nullptr; nw.counters = nullptr;
   MONO_TRY(alloc_arrays(&nw, new_cap));
@@ -1851,7 +1911,7 @@ static int rehash(Table* t, uint64_t new_cap, hipStream_t st) {
   MONO_HIP(hipStreamSynchronize(st));
   free_arrays(&t->d);
   t->d = nw;
-  return 0;
+  return keys_changed(t, st);
 }
 
 // Called before any launch that can insert up to `incoming` new keys.
@@ -2140,6 +2200,26 @@ static int bits_for(uint64_t max_value) {
   return b;
 }
 
+// Every call that may change the key set (inserts, rehash, evict, clear, import) drops a pending
+// hint and leaves an event behind itself: the next hint's probe waits for it.
+static int hint_drop(Table* t, hipStream_t st) {
+  // (a hint's probe reads the key array, which a rehash frees: the dropping call waits for it)
+  for (int k = 0; k < t->hint_count; ++k) {
+    Table::Hint& h = t->hints[(t->hint_head + k) % Table::kHintDepth];
+    MONO_HIP(hipStreamWaitEvent(st, h.p.ev_ready, 0));
+    h.p.chain_pending = false;
+    h.p.n = 0;
+  }
+  t->hint_count = 0;
+  return 0;
+}
+static int keys_changed(Table* t, hipStream_t st) {
+  if (!t->ev_keys) MONO_HIP(hipEventCreateWithFlags(&t->ev_keys, hipEventDisableTiming));
+  MONO_HIP(hipEventRecord(t->ev_keys, st));
+  t->ev_keys_set = true;
+  return 0;
+}
+
 // ---- prepared update order (Table::Prep) ------------------------------------------------------
 static int prep_mode() {  // MONO_PREP: 0 = never, 1 = when the calls follow the pattern (default), 2 = always
   static const int v = [] {
@@ -2149,12 +2229,16 @@ static int prep_mode() {  // MONO_PREP: 0 = never, 1 = when the calls follow the
   return v;
 }
 
-static int prep_setup(Table* t) {
-  Table::Prep& p = t->prep;
+static int prep_setup(Table* t, Table::Prep& p) {
   if (p.stream) return 0;
   // (a high-priority stream changes nothing here: what delays the sort beside the gather is
   // the depth of the memory queues, not the dispatch order — profiles/r02_b_step_timeline.txt)
-  MONO_HIP(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
+  hipStream_t& cs = t->chain_stream[t->preps_made & 1];
+  // (nor does a low-priority one for the hinted chains, or a smaller grid for their probe: 307 to
+  // 314 us per step whatever is set, profiles/r02_q_hint_variants.txt)
+  if (!cs) MONO_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  ++t->preps_made;
+  p.stream = cs;
   MONO_HIP(hipEventCreateWithFlags(&p.ev_probe, hipEventDisableTiming));
   MONO_HIP(hipEventCreateWithFlags(&p.ev_ready, hipEventDisableTiming));
   MONO_HIP(hipEventCreateWithFlags(&p.ev_verify, hipEventDisableTiming));
@@ -2168,36 +2252,86 @@ static int prep_setup(Table* t) {
   return 0;
 }
 
-static void prep_destroy(Table* t) {
-  Table::Prep& p = t->prep;
-  if (p.stream) (void)hipStreamSynchronize(p.stream);
+static void prep_destroy_one(Table::Prep& p) {
   if (p.ev_probe) (void)hipEventDestroy(p.ev_probe);
   if (p.ev_ready) (void)hipEventDestroy(p.ev_ready);
   if (p.ev_verify) (void)hipEventDestroy(p.ev_verify);
   if (p.ev_gated) (void)hipEventDestroy(p.ev_gated);
-  if (p.stream) (void)hipStreamDestroy(p.stream);
   if (p.d_flags) (void)hipFree(p.d_flags);
   if (p.d_blk_miss) (void)hipFree(p.d_blk_miss);
   if (p.h_flags) (void)hipHostFree(p.h_flags);
   p.ws.release();
   p = Table::Prep{};
 }
+static void prep_destroy(Table* t) {
+  for (hipStream_t& cs : t->chain_stream)
+    if (cs) (void)hipStreamSynchronize(cs);
+  prep_destroy_one(t->prep);
+  for (Table::Hint& h : t->hints) {
+    prep_destroy_one(h.p);
+    if (h.ids) (void)hipFree(h.ids);
+    if (h.slots) (void)hipFree(h.slots);
+    h.ids = nullptr; h.slots = nullptr; h.cap = 0;
+  }
+  t->hint_head = t->hint_count = 0;
+  for (hipStream_t& cs : t->chain_stream) {
+    if (cs) (void)hipStreamDestroy(cs);
+    cs = nullptr;
+  }
+  t->preps_made = 0;
+  if (t->ev_hint_src) (void)hipEventDestroy(t->ev_hint_src);
+  if (t->ev_keys) (void)hipEventDestroy(t->ev_keys);
+  t->ev_hint_src = t->ev_keys = nullptr;
+  t->ev_keys_set = false;
+}
+
+// Row gather of a lookup from a slot record: `blocks` workgroups, `ilp` rows in flight per lane group.
+static int launch_gather(Table* t, const uint32_t* slots, int64_t n, float* out, bool aligned,
+                         int gather_blocks, int gather_ilp, hipStream_t gs) {
+  const int D = t->d.dim;
+#define MONO_GATHER(LPR, ILP)                                                                       \
+  hipLaunchKernelGGL((k_gather_rows4<LPR, ILP>), dim3(grid_for(n, (256 / LPR) * ILP, gather_blocks)), \
+                     dim3(256), 0, gs, t->d, slots, n, out)
+#define MONO_GATHER_L(LPR)                                  \
+  do {                                                      \
+    if (gather_ilp <= 1) MONO_GATHER(LPR, 1);               \
+    else if (gather_ilp <= 2) MONO_GATHER(LPR, 2);          \
+    else if (gather_ilp <= 4) MONO_GATHER(LPR, 4);          \
+    else MONO_GATHER(LPR, 8);                               \
+  } while (0)
+  if (D % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) {
+    if (D <= 16) MONO_GATHER_L(4);
+    else if (D <= 32) MONO_GATHER_L(8);
+    else MONO_GATHER_L(16);
+  } else {
+    hipLaunchKernelGGL(k_gather_rows1, dim3(grid_for(n, 32, gather_blocks)), dim3(256), 0, gs, t->d,
+                       slots, n, out);
+  }
+#undef MONO_GATHER_L
+#undef MONO_GATHER
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
 
 // mono_table_lookup, prepared form: k_probe on the caller's stream, then the row gather there
 // and the update order (sort by slot, k_classify) on the table's own stream beside it.
-static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, bool aligned,
-                           hipStream_t st) {
-  MONO_TRY(prep_setup(t));
-  Table::Prep& p = t->prep;
+// `hint`: mono_table_lookup_hint — the same for the NEXT lookup's ids, everything (probe included)
+// on the Prep's own stream `p.stream`, no gather, the slot record written to rec_ids / rec_slots.
+static int lookup_prepared(Table* t, Table::Prep& p, const int64_t* ids, int64_t n, float* out,
+                           bool aligned, hipStream_t st, bool hint, int64_t* rec_ids,
+                           uint32_t* rec_slots) {
+  MONO_TRY(prep_setup(t, p));
   p.n = 0;
+  p.hinted = hint;
   // (tried: the sort chain on the caller's stream and the gather beside it — the update's host
   // read-back then sits behind the whole chain: 376 us per step against 357)
   hipStream_t gs = st;        // row gather
   hipStream_t ss = p.stream;  // sort + classify
+  hipStream_t ps = hint ? ss : st;  // probe
   // A lookup that follows another one with no update in between: the chain of the earlier
   // lookup may still be running, and k_probe below resets the counters that chain's k_classify
   // adds to (a stale increment would make the next k_apply read heads nobody wrote).
-  if (p.chain_pending) MONO_HIP(hipStreamWaitEvent(st, p.ev_ready, 0));
+  if (p.chain_pending && !hint) MONO_HIP(hipStreamWaitEvent(st, p.ev_ready, 0));
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
   const int end_bit = bits_for(t->d.cap + 1);
   const size_t tmp_bytes = (sort_pairs_tmp_bytes((size_t)n, end_bit) + 255) & ~(size_t)255;
@@ -2209,11 +2343,11 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
   p.q_base = (char*)tmp + tmp_bytes;
   double hp = host_prof_on() ? host_now() : 0.0;
   p.probe_blocks = grid_for(n, 32 * kIlpP, kProbeMaxBlocks);
-  hipLaunchKernelGGL(k_probe, dim3(p.probe_blocks), dim3(256), 0, st, t->d, ids, n, t->cache_ids,
-                     t->cache_slots, p.d_blk_miss, (uint32_t*)p.q_base, p.d_flags);
+  hipLaunchKernelGGL(k_probe, dim3(p.probe_blocks), dim3(256), 0, ps, t->d, ids, n, rec_ids, rec_slots,
+                     p.d_blk_miss, (uint32_t*)p.q_base, p.d_flags);
   MONO_HIP(hipGetLastError());
   host_tick("lookup: launch probe", &hp);
-  MONO_HIP(hipEventRecord(p.ev_probe, st));
+  MONO_HIP(hipEventRecord(p.ev_probe, ps));
   host_tick("lookup: record probe", &hp);
   // Row gather on the caller's stream, deliberately throttled: one workgroup per CU, two rows in
   // flight per lane group. At full depth (4096 workgroups x 8 rows) the gather keeps hundreds of
@@ -2226,7 +2360,6 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
   // with other work in between (the sharded pipeline: row exchange, F2 gather, gradient sum) the
   // order is ready long before, and the throttle only slows the gather down. try_prepared sees
   // which case it is (was the order complete when the update asked?) and flips gather_full.
-  const int D = t->d.dim;
   static const int env_blocks = [] {
     const char* e = getenv("MONO_GATHER_BLOCKS");
     return e ? atoi(e) : 0;
@@ -2238,35 +2371,14 @@ static int lookup_prepared(Table* t, const int64_t* ids, int64_t n, float* out, 
   const bool full = p.gather_full && env_blocks == 0 && env_ilp == 0;
   const int gather_blocks = env_blocks ? env_blocks : full ? 4096 : 256;
   const int gather_ilp = env_ilp ? env_ilp : full ? 8 : 2;
-#define MONO_GATHER(LPR, ILP)                                                                       \
-  hipLaunchKernelGGL((k_gather_rows4<LPR, ILP>), dim3(grid_for(n, (256 / LPR) * ILP, gather_blocks)), \
-                     dim3(256), 0, gs, t->d, t->cache_slots, n, out)
-#define MONO_GATHER_L(LPR)                                  \
-  do {                                                      \
-    if (gather_ilp <= 1) MONO_GATHER(LPR, 1);               \
-    else if (gather_ilp <= 2) MONO_GATHER(LPR, 2);          \
-    else if (gather_ilp <= 4) MONO_GATHER(LPR, 4);          \
-    else MONO_GATHER(LPR, 8);                               \
-  } while (0)
-  if (!out) {
-    // slots only (table_lookup_slots: the fused lookup + pool gathers the rows itself)
-  } else if (D % 4 == 0 && t->d.row_floats % 4 == 0 && aligned) {
-    if (D <= 16) MONO_GATHER_L(4);
-    else if (D <= 32) MONO_GATHER_L(8);
-    else MONO_GATHER_L(16);
-  } else {
-    hipLaunchKernelGGL(k_gather_rows1, dim3(grid_for(n, 32, gather_blocks)), dim3(256), 0, gs, t->d,
-                       t->cache_slots, n, out);
-  }
-#undef MONO_GATHER_L
-#undef MONO_GATHER
-  MONO_HIP(hipGetLastError());
+  // (out == nullptr: slots only — table_lookup_slots, the fused lookup + pool gathers the rows itself)
+  if (out && !hint) MONO_TRY(launch_gather(t, rec_slots, n, out, aligned, gather_blocks, gather_ilp, gs));
   host_tick("lookup: launch gather", &hp);
   // update order beside it
-  MONO_HIP(hipStreamWaitEvent(ss, p.ev_probe, 0));
+  if (!hint) MONO_HIP(hipStreamWaitEvent(ss, p.ev_probe, 0));
   host_tick("lookup: ss wait probe", &hp);
-  MONO_TRY(sort_pairs_u32(t->cache_slots, p.sslots, nullptr, p.sidx, (size_t)n, end_bit, tmp,
-                          tmp_bytes, ss));
+  MONO_TRY(sort_pairs_u32(rec_slots, p.sslots, nullptr, p.sidx, (size_t)n, end_bit, tmp, tmp_bytes,
+                          ss));
   host_tick("lookup: sort launches", &hp);
   ApplyArgs a{};
   a.skip_slot = kNoSlot;
@@ -2306,10 +2418,14 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
                      p.d_flags, (uint32_t*)p.q_base + 4, p.d_blk_miss, p.probe_blocks);
   MONO_HIP(hipGetLastError());
   host_tick("update: launch verify", &hp);
-  MONO_HIP(hipMemcpyAsync(p.h_flags, p.d_flags, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  MONO_HIP(hipMemcpyAsync(p.h_flags, p.d_flags, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   host_tick("update: memcpy flags", &hp);
   MONO_HIP(hipEventRecord(p.ev_verify, st));
   host_tick("update: record verify", &hp);
+  // (tried twice: the apply kernels launched before the host has the verdict, reading the same
+  // flags on the device and doing nothing on "no". Without hints the step is bound by the sort
+  // chain and nothing changes (364 against 355 us); with hints the apply starts 20 us earlier and
+  // runs 50 us longer, beside more of the next chains: 323 against 309 us.)
   MONO_HIP(hipEventSynchronize(p.ev_verify));
   host_tick("update: sync verify (incl. GPU wait)", &hp);
   const bool changed = p.h_flags[1] != p.seen_changed;
@@ -2317,8 +2433,12 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   // other ids, or unknown ids to insert (unless the caller handles those itself: the gated path,
   // where the prepared order serves the ids the table holds and skips the rest): full path
   const uint32_t missed = p.h_flags[0];  // of the lookup this order was built by
-  if ((missed != 0 && !allow_missing) || changed) {
+  // (a hinted order whose lookup met other ids than the hinted ones was sorted for the wrong slots)
+  const bool hint_off = p.hinted && p.h_flags[2] != 0;
+  if ((missed != 0 && !allow_missing) || changed || hint_off) {
     p.n = 0;
+    // (the lookups have left the hinted sequence: what is still queued would miss as well)
+    if (hint_off) MONO_TRY(hint_drop(t, st));
     return 0;
   }
   if (n_missing) *n_missing = (int64_t)missed;
@@ -2444,7 +2564,7 @@ static int write_path_gated(Table* t, void* filter, ApplyArgs a, const int64_t* 
   int32_t h_last[2] = {0, 0};
   MONO_HIP(hipMemcpyAsync(&h_last[0], pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
   MONO_HIP(hipMemcpyAsync(&h_last[1], unknown + (n - 1), 4, hipMemcpyDeviceToHost, st));
-  MONO_TRY(prep_setup(t));  // (its event marks the read-back below)
+  MONO_TRY(prep_setup(t, t->prep));  // (its event marks the read-back below)
   MONO_HIP(hipEventRecord(t->prep.ev_verify, st));
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
   // known ids: the plain path; it runs while the host waits for the count of unknown ones
@@ -2545,6 +2665,13 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   if (++t->updates_since_strike >= 64) t->updates_since_strike = t->prep_strikes = 0;
   t->expect_update = pattern && t->prep_strikes < 2;
   if (prepared && !from_keys) return 0;
+  // everything below may insert keys (and move them: rehash): a pending hint is stale, and the
+  // next one waits for what this call enqueues
+  MONO_TRY(hint_drop(t, st));
+  struct KeysDone {
+    Table* t; hipStream_t st;
+    ~KeysDone() { (void)keys_changed(t, st); }
+  } keys_done{t, st};
   if (!prepared) MONO_TRY(ensure_room(t, n, st));
 
   ApplyArgs a{};
@@ -2865,9 +2992,35 @@ static int lookup_impl(Table* t, const int64_t* ids, int64_t n, float* out, hipS
   MONO_REQUIRE(out || t->cache_n, "lookup_impl: a slots-only lookup needs the slot record");
   // a second lookup with no update in between: not the training pattern (any more)
   if (++t->lookups_since_update > 1) t->expect_update = false;
+  Table::Hint* oldest = t->hint_count ? &t->hints[t->hint_head] : nullptr;
+  if (t->cache_n && oldest && oldest->p.n == n && oldest->cap >= n) {
+    // A hint for a lookup of this size: its slot record and update order take the place of the
+    // current ones (the buffers swap roles), the ids are checked against the hinted ones on the
+    // device (k_hint_fix corrects the record where they differ and counts: the order is then not
+    // used), and all that is left of the lookup is the row gather, at full depth.
+    std::swap(t->prep, oldest->p);
+    std::swap(t->cache_ids, oldest->ids);
+    std::swap(t->cache_slots, oldest->slots);
+    std::swap(t->cache_cap, oldest->cap);
+    oldest->p.n = 0;
+    t->hint_head = (t->hint_head + 1) % Table::kHintDepth;
+    --t->hint_count;
+    Table::Prep& p = t->prep;
+    // (the whole chain, not just the probe: k_hint_fix may rewrite slots the sort is reading. In
+    // steady state the chain finished long ago, beside the update before this lookup.)
+    MONO_HIP(hipStreamWaitEvent(st, p.ev_ready, 0));
+    p.chain_pending = false;
+    hipLaunchKernelGGL(k_hint_fix, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, st, t->d, ids, n,
+                       t->cache_ids, t->cache_slots, p.d_flags);
+    MONO_HIP(hipGetLastError());
+    if (out) MONO_TRY(launch_gather(t, t->cache_slots, n, out, aligned, 4096, 8, st));
+    return 0;
+  }
+  if (t->hint_count) MONO_TRY(hint_drop(t, st));  // (a lookup of another size: not the hinted one)
   t->prep.n = 0;  // the record it was built from is being overwritten
   if (t->cache_n && prep_mode() != 0 && (t->expect_update || prep_mode() == 2))
-    return lookup_prepared(t, ids, n, out, aligned, st);
+    return lookup_prepared(t, t->prep, ids, n, out, aligned, st, /*hint=*/false, t->cache_ids,
+                           t->cache_slots);
   if (!out) {
     hipLaunchKernelGGL(k_resolve, dim3(grid_for(n, 32 * kIlpP)), dim3(256), 0, st, t->d, ids, n,
                        t->cache_slots, t->cache_ids);
@@ -2880,6 +3033,40 @@ static int lookup_impl(Table* t, const int64_t* ids, int64_t n, float* out, hipS
   else if (t->d.dim % 2 == 0 && t->d.row_floats % 2 == 0 && aligned) launch_lookup<2>(t, ids, n, out, st, ci, cs);
   else launch_lookup<1>(t, ids, n, out, st, ci, cs);
   MONO_HIP(hipGetLastError());
+  return 0;
+}
+
+// mono_table_lookup_hint: `ids` (ready on `hs`) are the ids of the mono_table_lookup `ahead` calls
+// from now on this table (1 = the next one). No-op unless the calls follow the training pattern
+// (lookup, update, lookup, ...).
+static int lookup_hint(Table* t, const int64_t* ids, int64_t n, int ahead, hipStream_t hs) {
+  if (n == 0 || !slot_cache_enabled() || prep_mode() == 0 || n >= (int64_t)0xFFFFFFF0ll) return 0;
+  if (!t->expect_update && prep_mode() != 2) return 0;
+  // only a hint that extends the queue by one is taken: the caller can announce "next" and "the
+  // one after" at every step without keeping track of what the table dropped or ignored
+  if (ahead != t->hint_count + 1 || ahead > Table::kHintDepth) return 0;
+  Table::Hint& h = t->hints[(t->hint_head + t->hint_count) % Table::kHintDepth];
+  if (n > h.cap) {  // (hipFree synchronises the device: nothing is reading the old buffers)
+    if (h.ids) (void)hipFree(h.ids);
+    if (h.slots) (void)hipFree(h.slots);
+    h.ids = nullptr; h.slots = nullptr; h.cap = 0;
+    MONO_HIP(hipMalloc((void**)&h.ids, (size_t)n * sizeof(int64_t)));
+    MONO_HIP(hipMalloc((void**)&h.slots, (size_t)n * sizeof(uint32_t)));
+    h.cap = n;
+  }
+  Table::Prep& p = h.p;
+  MONO_TRY(prep_setup(t, p));
+  if (!t->ev_hint_src) MONO_HIP(hipEventCreateWithFlags(&t->ev_hint_src, hipEventDisableTiming));
+  // The probe reads `ids` on the chain stream, some time after this call: they have to stay valid
+  // until the lookup they announce has been issued (the caller holds that batch anyway; a copy on
+  // the caller's stream would put 13 us into every step: profiles/r02_q_hint_timeline_copy.txt).
+  // It also reads the key array: it waits for the last call that may have changed the key set,
+  // NOT for updates through the prepared order, which never do.
+  MONO_HIP(hipEventRecord(t->ev_hint_src, hs));
+  MONO_HIP(hipStreamWaitEvent(p.stream, t->ev_hint_src, 0));
+  if (t->ev_keys_set) MONO_HIP(hipStreamWaitEvent(p.stream, t->ev_keys, 0));
+  MONO_TRY(lookup_prepared(t, p, ids, n, nullptr, false, hs, /*hint=*/true, h.ids, h.slots));
+  ++t->hint_count;
   return 0;
 }
 
@@ -3086,6 +3273,12 @@ int mono_table_lookup(void* table, const int64_t* ids, int64_t n, float* out, vo
   return lookup_impl((Table*)table, ids, n, out, (hipStream_t)stream);
 }
 
+int mono_table_lookup_hint(void* table, const int64_t* ids, int64_t n, int ahead, void* stream) {
+  MONO_REQUIRE(table && (n == 0 || ids), "mono_table_lookup_hint: null argument");
+  MONO_REQUIRE(ahead >= 1, "mono_table_lookup_hint: ahead = %d (1 = the next lookup)", ahead);
+  return lookup_hint((Table*)table, ids, n, ahead, (hipStream_t)stream);
+}
+
 int mono_table_assign(void* table, void* filter, const int64_t* ids, const float* values, int64_t n,
                       int64_t req_time, void* stream) {
   MONO_REQUIRE(table, "mono_table_assign: null table");
@@ -3168,11 +3361,12 @@ int mono_table_lookup_entry(void* table, const int64_t* ids, int64_t n, float* r
 int mono_table_clear(void* table, void* stream) {
   MONO_REQUIRE(table, "mono_table_clear: null table");
   Table* t = (Table*)table;
+  MONO_TRY(hint_drop(t, (hipStream_t)stream));
   MONO_TRY(reset_arrays(&t->d, (hipStream_t)stream));
   t->used_upper = 0;
   t->cache_n = 0;
   t->prep.n = 0;
-  return 0;
+  return keys_changed(t, (hipStream_t)stream);
 }
 
 int mono_table_evict(void* table, int64_t max_update_time, void* stream) {
@@ -3180,10 +3374,11 @@ int mono_table_evict(void* table, int64_t max_update_time, void* stream) {
   Table* t = (Table*)table;
   t->cache_n = 0;  // evicted slots may be claimed by other keys
   t->prep.n = 0;
+  MONO_TRY(hint_drop(t, (hipStream_t)stream));
   hipLaunchKernelGGL(k_evict, dim3(grid_for((int64_t)t->d.cap + 2, 256)), dim3(256), 0,
                      (hipStream_t)stream, t->d, max_update_time);
   MONO_HIP(hipGetLastError());
-  return 0;
+  return keys_changed(t, (hipStream_t)stream);
 }
 
 int mono_table_max_update_ts(void* table, int64_t* h_out) {

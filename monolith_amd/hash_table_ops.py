@@ -237,6 +237,20 @@ class HashTable(BaseHashTable):
                                           _lib.vp(out), _lib.stream_ptr()))
     return out
 
+  def lookup_hint(self, ids, ahead=1) -> None:
+    """mono_table_lookup_hint (no counterpart in the reference's op set; include/monolith_hip.h):
+    `ids` are the ids of the lookup() `ahead` calls from now (1 = the next one) — call it between a
+    lookup and its update, when the coming batches are already known, and those lookups only have
+    to gather rows. Never changes a result."""
+    ids = _ids(ids)
+    # (the library reads the ids later, on a stream of its own: keep the tensor — possibly a
+    # converted copy — alive until the lookups it can still be queued for have passed)
+    keep = self._table.__dict__.setdefault("_hint_keep", [])
+    keep.append(ids)
+    del keep[:-8]
+    _lib.check(_lib.lib.mono_table_lookup_hint(self._h(), _lib.vp(ids), C.c_int64(ids.numel()),
+                                               C.c_int(ahead), _lib.stream_ptr()))
+
   def lookup_entry(self, ids) -> List[bytes]:
     """hash_table_ops.py:278-281 -> HashTableLookupEntryOp: one serialized EntryDump per id
     (without the id field: Save() of the accessor does not set it), b"" for ids not in the table."""

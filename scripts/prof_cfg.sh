@@ -11,5 +11,5 @@ timeout -k 10 280 rocprofv3 --kernel-trace --stats -d $O/prof_$T -o p -- python3
 cd $R
 DB=$(find $O/prof_$T -name '*.db' | head -1)
 python3 scripts/db_to_stats.py $DB $O/${T}_kernel_stats_all.csv
-python3 scripts/timeline.py $DB $A > $O/${T}_timeline.txt
+python3 scripts/timeline.py $DB $A ${TIMELINE_BACK:-0} > $O/${T}_timeline.txt
 rm -rf $O/prof_$T

@@ -101,6 +101,9 @@ class HipTable:
   def lookup(self, ids):
     return self.t.lookup(np.asarray(ids, np.int64)).cpu().numpy()
 
+  def lookup_hint(self, ids, ahead=1):
+    self.t.lookup_hint(np.asarray(ids, np.int64), ahead)
+
   def assign(self, ids, values, req_time=0, filt=None):
     self.t = self._with_filter(filt).assign(np.asarray(ids, np.int64), np.asarray(values, np.float32),
                                             req_time)

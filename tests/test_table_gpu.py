@@ -378,6 +378,82 @@ def test_training_loop_prepared_update_order(name):
   assert o.max_update_ts() == h.max_update_ts()
 
 
+@pytest.mark.parametrize("depth", [1, 2, 3])
+@pytest.mark.parametrize("name", ["adagrad16", "multi3"])
+def test_lookup_hint_never_changes_a_result(name, depth):
+  """mono_table_lookup_hint (include/monolith_hip.h; no reference counterpart): the ids of the next
+  lookup announced between a lookup and its update. The step loop lookup(t) -> hint(t+1) ->
+  update(t) gives the oracle's rows and table state bit for bit — when the hint is right (the
+  hinted slot record and update order are used), when the next lookup brings other ids of the same
+  size (partly or wholly), another size, when the update in between inserts new keys, when
+  eviction / clear / growth come between hint and lookup, when a hint is never consumed, and when
+  the update after a hinted lookup is for other ids. depth: how many lookups ahead the loop
+  announces (every step announces all of 1..depth; the table takes what extends its queue)."""
+  cfg = CFGS[name]
+  o, h, _, _ = _pair(cfg)
+  D = sum(sg["dim"] for sg in cfg["segments"])
+  nlr = len(cfg["segments"])
+  rng = np.random.Generator(np.random.PCG64(zlib.crc32(name.encode()) + 5))
+  n, vocab = 20000, 2500
+  lrs = [0.05, 0.02, 0.1][:nlr]
+  o.assign_add(np.arange(vocab), np.zeros((vocab, D), np.float32), req_time=1)
+  h.assign_add(np.arange(vocab), np.zeros((vocab, D), np.float32), req_time=1)
+
+  def batch(step, size=n):
+    r = np.random.Generator(np.random.PCG64(1000 + step))
+    ids = r.integers(0, vocab, size).astype(np.int64)
+    ids[r.integers(0, size, size // 4)] = 7      # a hot key (long segment, split chunks)
+    if step in (6, 13):                          # ids nobody has seen: the update inserts them
+      ids[r.integers(0, size, 40)] = vocab + 100 * step + np.arange(40)
+    return ids
+
+  steps = 20
+  for step in range(steps):
+    ids = batch(step)
+    if step == 4:                                # a lookup of other ids than the hinted ones
+      ids = batch(100 + step)
+    if step == 5:                                # ... of a few other ids
+      ids = ids.copy()
+      ids[rng.integers(0, n, 17)] = rng.integers(0, vocab + 50, 17)
+    if step == 8:                                # ... of another size
+      ids = batch(step, n - 333)
+    g = rng.normal(0, 0.1, (len(ids), D)).astype(np.float32)
+    want, got = o.lookup(ids), h.lookup(ids)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), step
+    for ahead in range(1, depth + 1):
+      h.lookup_hint(batch(step + ahead), ahead)
+    if step == 10:                               # hints out of turn: ignored, or queued and wrong
+      h.lookup_hint(batch(200), depth + 1)
+      h.lookup_hint(batch(201), 1)
+    upd = ids
+    if step == 11:                               # the update after a hinted lookup: other ids
+      upd = batch(300)
+    dedup = step % 3 != 1
+    o.apply_gradients(upd, g, lrs, req_time=100 + step, global_step=step, enable_dedup=dedup)
+    h.apply_gradients(upd, g, lrs, req_time=100 + step, global_step=step, enable_dedup=dedup)
+    if step == 14:                               # eviction between hint and lookup
+      o.evict(50)
+      h.evict(50)
+    if step == 15:                               # growth (rehash) between hint and lookup
+      big = np.arange(50_000, 250_000, dtype=np.int64)
+      o.assign_add(big, np.ones((len(big), D), np.float32), req_time=100 + step)
+      h.assign_add(big, np.ones((len(big), D), np.float32), req_time=100 + step)
+    if step == 17:                               # clear between hint and lookup
+      o.clear()
+      h.clear()
+      o.assign_add(np.arange(vocab), np.zeros((vocab, D), np.float32), req_time=1)
+      h.assign_add(np.arange(vocab), np.zeros((vocab, D), np.float32), req_time=1)
+    oi, orows, ots = o.export()
+    hi, hrows, hts = h.export()
+    assert np.array_equal(oi, hi) and np.array_equal(ots, hts), step
+    hot = (oi == 7) if dedup else np.zeros(len(oi), bool)
+    assert np.array_equal(orows[~hot].view(np.uint32), hrows[~hot].view(np.uint32)), step
+    np.testing.assert_allclose(hrows[hot], orows[hot], rtol=1e-4, atol=1e-5)
+    if hot.any():                                # keep the two in step on the hot row
+      o.import_rows(oi[hot], hrows[hot], hts[hot])
+  _assert_same_state(o, h)
+
+
 def test_lookup_entry_and_extract_slot():
   """hash_table_ops_test.py:100-114 (entries of ids 0..2 parse, id 3 -> b""),
   embedding_hash_table_test.h:78-93 (the dump of an SGD dim-1 entry holding 1.0, byte for byte:
