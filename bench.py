@@ -658,15 +658,18 @@ def main():
   stream = torch.cuda.current_stream(device)
   sp = C.c_void_p(stream.cuda_stream)
 
-  def step(i):
-    ids = pool[i % n_pool]
-    _lib.check(_lib.lib.mono_table_lookup(h, _lib.vp(ids), C.c_int64(n), _lib.vp(out), sp))
+  def hint(i):
     if not args.no_hint:
-      # the input pipeline knows the next batch while this one trains (the reference prefetches
-      # batches the same way): its slots and update order are resolved beside this step's update
+      # the input pipeline knows the next batches while this one trains (the reference prefetches
+      # batches the same way): their slots and update orders are resolved beside this step's update
       for ahead in range(1, args.hint_ahead + 1):  # (the table takes the one that extends its queue)
         _lib.check(_lib.lib.mono_table_lookup_hint(h, _lib.vp(pool[(i + ahead) % n_pool]),
                                                    C.c_int64(n), C.c_int(ahead), sp))
+
+  def step(i):
+    ids = pool[i % n_pool]
+    _lib.check(_lib.lib.mono_table_lookup(h, _lib.vp(ids), C.c_int64(n), _lib.vp(out), sp))
+    hint(i)
     _lib.check(_lib.lib.mono_table_apply_gradients(h, None, _lib.vp(ids), _lib.vp(grad),
                                                    C.c_int64(n), lrs, C.c_int(1), C.c_int64(10 + i),
                                                    C.c_int64(i), C.c_int(1), sp))
@@ -695,11 +698,12 @@ def main():
   ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
   lk, ph = [], []
   ms3 = (C.c_float * 3)()
-  for i in range(10):
+  for i in range(args.warmup + args.steps, args.warmup + args.steps + 10):  # (the hinted sequence goes on)
     ids = pool[i % n_pool]
     ev0.record(stream)
     _lib.check(_lib.lib.mono_table_lookup(h, _lib.vp(ids), C.c_int64(n), _lib.vp(out), sp))
     ev1.record(stream)
+    hint(i)
     _lib.check(_lib.lib.mono_table_apply_gradients(h, None, _lib.vp(ids), _lib.vp(grad),
                                                    C.c_int64(n), lrs, C.c_int(1), C.c_int64(99),
                                                    C.c_int64(i), C.c_int(1), sp))
@@ -732,7 +736,10 @@ def main():
   # row/state read+write + ts (the part of §8d's update figure this kernel moves)
   # (mono_table_lookup = k_probe + k_gather_rows once the lookup -> update pattern is seen: the
   # sort of the update order then runs beside the row gather, and the update's "resolve" is
-  # k_verify + an 8-byte read-back, its "sort" the residual wait for the prepared order)
+  # k_verify + a 12-byte read-back, its "sort" the residual wait for the prepared order. With
+  # hints the probe, the sort and k_classify of a batch ran two steps earlier beside the updates
+  # of the batches before: mono_table_lookup = k_hint_fix + k_gather_rows, and those updates'
+  # kernels — k_apply here — are timed with the chains of later batches running beside them)
   kern = {
       "k_lookup": (lk_ms, lookup_bytes),
       "resolve (k_verify / k_claim_pending)": (find_ms, n * (8 + 8)),
@@ -757,7 +764,7 @@ def main():
     with open(pmc_file) as f:
       pmc = json.load(f)["kernels"]
     members = (["mono::k_apply<2, 1, 3>"] if kapply_ms == kapply_ms else
-               ["mono::k_classify", "mono::k_apply<2, 1, 3>", "mono::k_apply_long<1, 3>",
+               ["mono::k_classify", "mono::k_apply<2, 1, 3>", "mono::k_apply_long<1, 3, 1, 6144>",
                 "mono::k_combine<1>"])
     if args.batch == 65536 and args.rows == 1e8 and args.skew == 3.0:
       traffic = sum((pmc[m]["FETCH_SIZE_KB_last_launch"] + pmc[m]["WRITE_SIZE_KB_last_launch"]) *
