@@ -1,6 +1,8 @@
 """GPU parity: the HIP table through the C ABI vs the CPU oracle and the reference's vectors."""
 import zlib
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -162,6 +164,9 @@ def test_hot_key_bound_at_config2_shape():
     cold = oi != hot
     assert np.array_equal(orows[cold].view(np.uint32), hrows[cold].view(np.uint32))
     ro, rh, rx = orows[~cold][0], hrows[~cold][0], xrows[~cold][0]
+    if os.environ.get("MONO_EXACT_ORDER", "0") not in ("", "0"):
+      # strict input order at any length (test_layout_gpu's exact-order child process runs this)
+      assert np.array_equal(ro.view(np.uint32), rh.view(np.uint32)), step
     for part in (slice(0, D), slice(D, 2 * D)):  # weights, Adagrad accumulator
       scale = np.abs(rx[part]).max()
       worst_rel = max(worst_rel, np.abs(rh[part] - ro[part]).max() / scale)
