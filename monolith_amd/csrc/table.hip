@@ -1439,8 +1439,8 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
 // further ahead through an LDS ring, so a row load never waits on an index load): ~800 rows of
 // 64 bytes are in flight per workgroup, which is what hides an HBM round trip at the rate the
 // consumer walks. Wave 0 only consumes: lane e owns column e and adds / steps the rows of the
-// row-major LDS tile in input order, eight LDS reads in flight — bit-exact with the sequential
-// reference, one dependent floating-point add per row.
+// column-major LDS tile in input order, four rows per 16-byte LDS load, sixteen rows in flight —
+// bit-exact with the sequential reference, one dependent floating-point add per row.
 constexpr int kLoaders = 192;
 constexpr int kLTileFloatsDefault = 6144;      // 24 KB per LDS tile, 8 float4 per loader thread
 constexpr int kLMaxRows = 2 * kLoaders;        // rows per tile (two prefetched indices per thread)
@@ -1476,7 +1476,7 @@ __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a
     __syncthreads();
     if (tid == 0) s_qi = atomicAdd(&a.qcount[4], 1u);
     __syncthreads();
-    const uint32_t qi = s_qi;
+    const uint32_t qi = __builtin_amdgcn_readfirstlane(s_qi);  // (uniform: ls lives in SGPRs)
     if (qi >= nq) break;
     const LongSeg ls = a.queue[qi];
     float* row = t.rows + (uint64_t)ls.slot * R;
@@ -1484,7 +1484,11 @@ __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a
       const int Dw = min(64, D - eb);     // columns of this pass
       // rows per tile; the per-thread walk over the tile's (row, column) cells, without a
       // division per cell: cell k * kLoaders + lt, cells = float4 quads (vec4) or floats
-      const int rpt = max(1, min(kLMaxRows, kLTileFloats / Dw));
+      // The LDS tile is column-major, [column][RS]: the consumer's lane e then reads FOUR
+      // consecutive rows of its column with one 16-byte LDS load. RS = 4 * odd spreads the lanes'
+      // loads (and the loaders' transposed stores) over the banks.
+      const int RS = ((min(kLMaxRows, kLTileFloats / Dw) - 4) & ~7) + 4;
+      const int rpt = RS;
       const int64_t ntiles = (ls.end - ls.first + rpt - 1) / rpt;
       const int cpr = vec4 ? Dw / 4 : Dw;  // cells per row
       const int r0 = loader ? lt / cpr : 0, c0 = loader ? lt - r0 * cpr : 0;
@@ -1502,7 +1506,6 @@ __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a
       float w = 0.f, s0 = 0.f, s1 = 0.f, acc = 0.f;
       OptX ox;
       ox.gstep = a.global_step;
-      bool have_acc = false;
       const bool need_state = MODE == MODE_OPT_SEQ || MODE == MODE_OPT_DEDUP;
       const bool part = ls.part != kNoPart;  // one chunk of a split key: emit the chunk sum only
       if (owner && !part && MODE != MODE_SET_SUM) {
@@ -1554,13 +1557,19 @@ __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a
           }
         }
       };
-      auto put = [&](const float4(&S)[kLStage4], int buf) {  // row-major [row][Dw] store
+      auto put = [&](const float4(&S)[kLStage4], int buf) {  // column-major [column][RS] store
         if (!loader) return;
         int r = r0, c = c0;
         if (vec4) {
 #pragma unroll
           for (int k = 0; k < kLStage4; ++k) {
-            if (r < rpt) *reinterpret_cast<float4*>(&tile[buf][r * Dw + 4 * c]) = S[k];
+            if (r < rpt) {
+              float* q = &tile[buf][4 * c * RS + r];
+              q[0] = S[k].x;
+              q[RS] = S[k].y;
+              q[2 * RS] = S[k].z;
+              q[3 * RS] = S[k].w;
+            }
             r += dr;
             c += dc;
             if (c >= cpr) { c -= cpr; ++r; }
@@ -1569,7 +1578,7 @@ __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a
           const float* Sf = reinterpret_cast<const float*>(&S[0]);
 #pragma unroll
           for (int k = 0; k < 4 * kLStage4; ++k) {
-            if (r < rpt) tile[buf][r * Dw + c] = Sf[k];
+            if (r < rpt) tile[buf][c * RS + r] = Sf[k];
             r += dr;
             c += dc;
             if (c >= cpr) { c -= cpr; ++r; }
@@ -1584,41 +1593,56 @@ __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a
       auto compute = [&](int64_t tl, int buf) {  // wave 0: walk the tile in input order
         if (!owner) return;
         const int rows = (int)min((int64_t)rpt, ls.end - (ls.first + tl * rpt));
-        const float* tp = &tile[buf][tid];
-        int r = 0;
-        if (kSums && !have_acc) {  // first row seeds the sum
-          acc = tp[0];
-          have_acc = true;
-          r = 1;
+        const float4* tp = reinterpret_cast<const float4*>(&tile[buf][tid * RS]);
+        const int G = rows >> 2, rem = rows & 3;  // whole groups of four rows, rows of the last one
+        int g = 0;                                // (uniform: the loop control below is scalar)
+        if (kSums && tl == 0) {                   // first row seeds the sum
+          const float4 x = tp[0];
+          acc = x.x;
+          if (rows > 1) step(x.y);
+          if (rows > 2) step(x.z);
+          if (rows > 3) step(x.w);
+          g = 1;
         }
-        // eight LDS reads in flight and the NEXT eight issued before this eight's dependent adds
-        // (two register sets, alternating): the chain then waits on its adds, not on LDS
-        if (r + 8 <= rows) {
-          float va[8], vb[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) va[k] = tp[(r + k) * Dw];
+        // A lone wave issues one instruction every four cycles, so the chain's cost is its
+        // instruction count: one LDS load per four rows, and the NEXT sixteen rows loaded before
+        // this sixteen's dependent adds (two register sets, alternating; the loads are
+        // unconditional — past the tile's rows they read stale LDS that is never used).
+#define MONO_STEP4(q) step(q.x); step(q.y); step(q.z); step(q.w)
+        if (g + 4 <= G) {
+          float4 a0 = tp[g], a1 = tp[g + 1], a2 = tp[g + 2], a3 = tp[g + 3];
           for (;;) {
-            const bool more_b = r + 16 <= rows;
-            if (more_b) {
-#pragma unroll
-              for (int k = 0; k < 8; ++k) vb[k] = tp[(r + 8 + k) * Dw];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) step(va[k]);
-            r += 8;
-            if (!more_b) break;
-            const bool more_a = r + 16 <= rows;
-            if (more_a) {
-#pragma unroll
-              for (int k = 0; k < 8; ++k) va[k] = tp[(r + 8 + k) * Dw];
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) step(vb[k]);
-            r += 8;
-            if (!more_a) break;
+            // (scheduling barriers: the compiler otherwise sinks these loads below the adds,
+            // next to the following set's, and waits for both before the first add)
+            // (and the explicit wait — lgkmcnt(0), nothing else — lets the set loaded sixteen adds
+            // ago land BEFORE the next loads are issued: placed after them it would wait for both)
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            const float4 b0 = tp[g + 4], b1 = tp[g + 5], b2 = tp[g + 6], b3 = tp[g + 7];
+            __builtin_amdgcn_sched_barrier(0);
+            MONO_STEP4(a0); MONO_STEP4(a1); MONO_STEP4(a2); MONO_STEP4(a3);
+            __builtin_amdgcn_sched_barrier(0);
+            g += 4;
+            if (g + 4 > G) break;
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            a0 = tp[g + 4]; a1 = tp[g + 5]; a2 = tp[g + 6]; a3 = tp[g + 7];
+            __builtin_amdgcn_sched_barrier(0);
+            MONO_STEP4(b0); MONO_STEP4(b1); MONO_STEP4(b2); MONO_STEP4(b3);
+            __builtin_amdgcn_sched_barrier(0);
+            g += 4;
+            if (g + 4 > G) break;
           }
         }
-        for (; r < rows; ++r) step(tp[r * Dw]);
+        for (; g < G; ++g) {
+          const float4 x = tp[g];
+          MONO_STEP4(x);
+        }
+#undef MONO_STEP4
+        if (rem != 0 && g == G) {  // (g > G: the seeding group above was the only, partial one)
+          const float4 x = tp[G];
+          step(x.x);
+          if (rem > 1) step(x.y);
+          if (rem > 2) step(x.z);
+        }
       };
       // one round: tile tl sits in LDS[tl & 1]; stage S carries tile tl + 1, the other stage
       // tile tl + 2. Park tl + 1, refill S with tl + 3, advance the index ring, consume tl.
