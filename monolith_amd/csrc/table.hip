@@ -1456,6 +1456,11 @@ template <int OPTK, int MODE, int OCC = 1, int TILE = kLTileFloatsDefault>
 __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a) {
   constexpr int kLTileFloats = TILE;                     // floats per LDS tile
   constexpr int kLStage4 = kLTileFloats / 4 / kLoaders;  // float4 per loader thread per tile
+  // Register stages = tiles in flight ahead of the consumer. Two are enough: with four (tiles
+  // tl + 1 .. tl + 4 in flight) a lone 30k-row chain beside k_apply takes the same 249 us — the
+  // chain is bound by the dependent add itself (~8 ns per row), not by the loaders.
+  constexpr int NS = 2;
+  static_assert(NS + 3 <= kLIdxRing, "index ring too short");
   static_assert(kLStage4 * 4 * kLoaders == kLTileFloats, "tile size must be a multiple of 4 * kLoaders");
   __shared__ __attribute__((aligned(16))) float tile[2][kLTileFloats];
   __shared__ uint32_t idxs[kLIdxRing][kLMaxRows];
@@ -1651,12 +1656,12 @@ __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a
         const int cur = (int)(tl & 1);
         if (tl + 1 < ntiles) put(S, cur ^ 1);
         if (loader) {
-          idxs[(tl + 4) & (kLIdxRing - 1)][lt] = nx0;
-          idxs[(tl + 4) & (kLIdxRing - 1)][lt + kLoaders] = nx1;
+          idxs[(tl + NS + 2) & (kLIdxRing - 1)][lt] = nx0;
+          idxs[(tl + NS + 2) & (kLIdxRing - 1)][lt + kLoaders] = nx1;
         }
-        nx0 = load_idx(tl + 5, 0);
-        nx1 = load_idx(tl + 5, 1);
-        issue(S, tl + 3);
+        nx0 = load_idx(tl + NS + 3, 0);
+        nx1 = load_idx(tl + NS + 3, 1);
+        issue(S, tl + NS + 1);
         compute(tl, cur);
         __syncthreads();
       };
@@ -1666,20 +1671,37 @@ __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-          for (int z = 0; z < 4; ++z) idxs[z][lt + h * kLoaders] = load_idx(z, h);
+          for (int z = 0; z < NS + 2; ++z) idxs[z][lt + h * kLoaders] = load_idx(z, h);
       }
       __syncthreads();
-      float4 Sa[kLStage4], Sb[kLStage4];
-      nx0 = load_idx(4, 0);
-      nx1 = load_idx(4, 1);
-      issue(Sa, 0);
-      put(Sa, 0);
-      issue(Sb, 1);  // tile 1 -> parked by round 0
-      issue(Sa, 2);  // tile 2 -> parked by round 1
-      __syncthreads();
-      for (int64_t tl = 0; tl < ntiles; tl += 2) {
-        round(tl, Sb);
-        if (tl + 1 < ntiles) round(tl + 1, Sa);
+      nx0 = load_idx(NS + 2, 0);
+      nx1 = load_idx(NS + 2, 1);
+      if constexpr (NS == 2) {
+        float4 Sa[kLStage4], Sb[kLStage4];
+        issue(Sa, 0);
+        put(Sa, 0);
+        issue(Sb, 1);  // tile 1 -> parked by round 0
+        issue(Sa, 2);  // tile 2 -> parked by round 1
+        __syncthreads();
+        for (int64_t tl = 0; tl < ntiles; tl += 2) {
+          round(tl, Sb);
+          if (tl + 1 < ntiles) round(tl + 1, Sa);
+        }
+      } else {  // four stages: tile k travels in stage k % 4, tiles tl + 1 .. tl + 4 are in flight
+        float4 Sa[kLStage4], Sb[kLStage4], Sc[kLStage4], Sd[kLStage4];
+        issue(Sa, 0);
+        put(Sa, 0);
+        issue(Sb, 1);
+        issue(Sc, 2);
+        issue(Sd, 3);
+        issue(Sa, 4);
+        __syncthreads();
+        for (int64_t tl = 0; tl < ntiles; tl += 4) {
+          round(tl, Sb);
+          if (tl + 1 < ntiles) round(tl + 1, Sc);
+          if (tl + 2 < ntiles) round(tl + 2, Sd);
+          if (tl + 3 < ntiles) round(tl + 3, Sa);
+        }
       }
       if (owner && part) {
         a.partials[(uint64_t)ls.part * D + e] = MODE == MODE_ASSIGN_ADD ? w : acc;

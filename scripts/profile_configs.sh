@@ -1,6 +1,6 @@
 #!/bin/bash
 # Bench line + rocprofv3 kernel stats of configs 3, 4 and 5 (BASELINE.json), and the sharded
-# pipeline on the config-2 shape at N=1:  scripts/profile_configs.sh r02_q
+# pipeline on the config-2 shape at N=1:  scripts/profile_configs.sh r02_r
 set -e -o pipefail
 T=$1
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One round's measurement set on the GPU box (run through gpurun from the repo root):
-#   scripts/profile_round.sh r02_q [anchor kernel of a step, default k_probe]
+#   scripts/profile_round.sh r02_r [anchor kernel of a step, default k_probe]
 # bench line, rocprofv3 --kernel-trace --stats of the same command, FETCH_SIZE / WRITE_SIZE passes
 # (each its own run), the sharded pipeline at N=1. Summaries land in gpurun_out/<tag>_*; the
 # rocprof databases are deleted on the box (gpurun_out is capped at 64 MiB).
