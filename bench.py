@@ -528,14 +528,28 @@ def main_config5(args, device):
   fresh_slot = (fresh_pos % len(SLOT_VOCAB)) << 48
   state = {"t": table, "fresh": 1 << 40, "evictions": 0}
 
-  def step(i):
+  # (experiment switch, off: with 5 % of every batch unknown to the table the hinted orders are
+  # dropped by the inserts they race with, and preparing them costs 795 against 503 us per step)
+  ahead = args.hint_ahead if args.c5_hint else 0
+  made = {}  # step -> its ids (made `ahead` steps early when the lookups are announced ahead)
+
+  def make_ids(i):
     ids = pool[i % n_pool].clone()
     # 5 % churn: ids nobody has seen (each occurs once this step; the filter counts them)
     ids[fresh_pos] = fresh_slot | (state["fresh"] + torch.arange(n_fresh, device=device))
     state["fresh"] += n_fresh // 3  # two thirds of a step's fresh ids come back in later steps
+    return ids
+
+  def step(i):
+    for j in range(i, i + ahead + 1):  # (the input pipeline runs `ahead` batches ahead)
+      if j not in made:
+        made[j] = make_ids(j)
+    ids = made.pop(i)
     now = now0 + 3600 * (i + 1)
     t = state["t"]
     t.lookup(ids)
+    for a in range(1, ahead + 1):
+      t.lookup_hint(made[i + a], a)
     state["t"] = t.apply_gradients(ids, grad, global_step=i, enable_dedup=True, req_time=now)
     if i % 24 == 23:
       state["t"].evict(now)
@@ -593,6 +607,8 @@ def main():
   ap.add_argument("--no-hint", action="store_true",
                   help="config 2: do not announce the next batch's ids (mono_table_lookup_hint) "
                        "between a step's lookup and its update")
+  ap.add_argument("--c5-hint", action="store_true",
+                  help="config 5: announce the next lookups as on config 2 (slower there; off)")
   ap.add_argument("--hint-ahead", type=int, default=2, help="config 2: lookups announced ahead (1..3)")
   ap.add_argument("--config", type=int, default=0, help="2 | 3 | 4 | 5 (default: 2, or 4 when N > 1)")
   ap.add_argument("--dim", type=int, default=0, help="config 4 / --sharded: row width (default 64 / 16)")

@@ -143,11 +143,15 @@ def test_config3_pooling_ftrl_pipeline(B, bag, bag_max, vocab):
     _same_state(o_t[t], h_t[t])
 
 
-def test_config5_streaming_filter_eviction():
+@pytest.mark.parametrize("ahead", [0, 2], ids=["plain", "hinted"])
+def test_config5_streaming_filter_eviction(ahead):
   """Online-training stream: sliding filter with occurrence threshold 3, 5 % of every step's ids
   from a fresh range, req_time advancing one hour per step, slots 1-3 expire after one day,
   evict every 24 steps. Ids carry distinct 12-bit filter signatures (alias-free by construction,
-  SURVEY.md 8c) and a batch never fills a filter block (no mid-batch rotation)."""
+  SURVEY.md 8c) and a batch never fills a filter block (no mid-batch rotation). "hinted": the
+  next two lookups are announced between every lookup and its update (mono_table_lookup_hint),
+  as bench.py does on config 2 — insertions by the gated update and evictions overtake hints all
+  the time here, and nothing may change."""
   fcfg = {"kind": "sliding", "capacity": 400000, "split_num": 7, "default_threshold": 3}
   tcfg = {"segments": [{"dim": 8, "opt": "adagrad", "init": "uniform", "init_a": -0.05,
                         "init_b": 0.05}], "seed": 9, "default_expire_days": 36500,
@@ -155,9 +159,10 @@ def test_config5_streaming_filter_eviction():
   of, hf = oracle_backend.make_filter(fcfg), hip_backend.make_filter(fcfg)
   o, h = oracle_backend.make_table(tcfg), hip_backend.make_table(tcfg, hf)
   rng = np.random.Generator(np.random.PCG64(13))
-  n, fresh_base = 600, 300
+  n, fresh_base, steps = 600, 300, 60
   uid = {}  # (slot, r) -> unique filter signature: at most 4096 distinct ids in the whole stream
-  for step in range(60):
+  stream = []
+  for step in range(steps + 2):
     slots = rng.integers(1, 7, n).astype(np.int64)
     r = (rng.zipf(1.3, n) % 300).astype(np.int64)
     fresh = rng.random(n) < 0.05
@@ -167,17 +172,21 @@ def test_config5_streaming_filter_eviction():
                    np.int64)
     assert len(uid) < 4096
     ids = (slots << 48) | (sig << 17) | 1   # signature = bits 17..28
-    g = rng.normal(0, 0.1, (n, 8)).astype(np.float32)
+    stream.append((ids, rng.normal(0, 0.1, (n, 8)).astype(np.float32)))
+  for step in range(steps):
+    ids, g = stream[step]
     now = 1_700_000_000 + 3600 * step
     eo, eh = o.lookup(ids), h.lookup(ids)
     assert np.array_equal(eo.view(np.uint32), eh.view(np.uint32)), step
+    for a in range(1, ahead + 1):
+      h.lookup_hint(stream[step + a][0], a)
     o.apply_gradients(ids, g, [0.02], req_time=now, global_step=step, enable_dedup=True, filt=of)
     h.apply_gradients(ids, g, [0.02], req_time=now, global_step=step, enable_dedup=True, filt=hf)
     if step % 24 == 23:
       o.evict(now); h.evict(now)
       assert o.size() == h.size()
   _same_state(o, h)
-  assert h.size() < 60 * n  # the filter kept one-off ids out, eviction removed stale rows
+  assert h.size() < steps * n  # the filter kept one-off ids out, eviction removed stale rows
   probe = np.unique(ids)
   assert np.array_equal(of.get(probe), hf.get(torch.as_tensor(probe).cuda()).cpu().numpy())
 
