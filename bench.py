@@ -528,9 +528,11 @@ def main_config5(args, device):
   fresh_slot = (fresh_pos % len(SLOT_VOCAB)) << 48
   state = {"t": table, "fresh": 1 << 40, "evictions": 0}
 
-  # (experiment switch, off: with 5 % of every batch unknown to the table the hinted orders are
-  # dropped by the inserts they race with, and preparing them costs 795 against 503 us per step)
-  ahead = args.hint_ahead if args.c5_hint else 0
+  # The next lookup is announced one step ahead (a gated update keeps the queued hints: an
+  # insertion moves no row, k_hint_fix probes the ids recorded as absent again). One ahead, not
+  # two as on config 2: 471 / 509 / 588 us per step with one / none / two (the re-probe of the
+  # 5 % absent ids makes k_hint_fix the expensive part of a hinted lookup here).
+  ahead = 0 if args.no_hint else args.c5_hint_ahead
   made = {}  # step -> its ids (made `ahead` steps early when the lookups are announced ahead)
 
   def make_ids(i):
@@ -569,8 +571,9 @@ def main_config5(args, device):
       "config": {"workload": "config 5: criteo-shaped stream (26 slots, %.3g rows, dim 16, Adagrad, "
                              "batch %d) + sliding hash filter (threshold 3, capacity 3e8, 7 blocks) "
                              "gating inserts, 5 %% fresh FIDs per step, req_time + 1 h per step, "
-                             "every second slot expires after 1 day, evict every 24 steps" %
-                             (total_rows, args.batch),
+                             "every second slot expires after 1 day, evict every 24 steps%s" %
+                             (total_rows, args.batch,
+                              ", the next batch's ids announced by lookup_hint" if ahead else ""),
                  "fids_per_step": n, "unique_ratio": uniq, "fresh_fids_per_step": n_fresh,
                  "rows_before": rows0, "rows_after": rows1, "evictions": state["evictions"],
                  "filter_state": {k: v for k, v in filt.state().items() if k != "num_elements"},
@@ -607,8 +610,8 @@ def main():
   ap.add_argument("--no-hint", action="store_true",
                   help="config 2: do not announce the next batch's ids (mono_table_lookup_hint) "
                        "between a step's lookup and its update")
-  ap.add_argument("--c5-hint", action="store_true",
-                  help="config 5: announce the next lookups as on config 2 (slower there; off)")
+  ap.add_argument("--c5-hint-ahead", type=int, default=1,
+                  help="config 5: lookups announced ahead (0..3; --no-hint = 0)")
   ap.add_argument("--hint-ahead", type=int, default=2, help="config 2: lookups announced ahead (1..3)")
   ap.add_argument("--config", type=int, default=0, help="2 | 3 | 4 | 5 (default: 2, or 4 when N > 1)")
   ap.add_argument("--dim", type=int, default=0, help="config 4 / --sharded: row width (default 64 / 16)")

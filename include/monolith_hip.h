@@ -167,8 +167,9 @@ int mono_table_lookup(void* table, const int64_t* ids, int64_t n, float* out, vo
  * resolves their slots and prepares the update order on streams of its own, beside the updates
  * of the batches before; the lookup they were announced for checks on the device that it got the
  * hinted ids and only gathers the rows. Purely an optimisation: results are the same with or
- * without the call, whatever ids follow (a hint that does not match, or that a key insertion /
- * eviction / clear has overtaken, is dropped). The table keeps a queue, oldest first, and takes a
+ * without the call, whatever ids follow (a hint that does not match, or that an eviction, a
+ * clear, a rehash or an ungated key insertion has overtaken, is dropped; insertions by an update
+ * gated by a hash filter keep it: the ids it recorded as absent are probed again). The table keeps a queue, oldest first, and takes a
  * hint only if it extends that queue by one (`ahead` == hints queued + 1): a caller may announce
  * ahead = 1 and ahead = 2 at every step, between the lookup and its update, and the table picks
  * what it does not have yet. Two ahead is what pays: beside an update the sort runs

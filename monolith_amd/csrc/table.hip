@@ -522,6 +522,10 @@ __global__ void __launch_bounds__(256) k_hint_fix(TableDev t, const int64_t* __r
        i0 += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = i0 + lane;
     const bool bad = i < n && ids[i] != rec_ids[i];
+    // An id the hinted probe did not find may have been inserted since (a gated update keeps the
+    // queued hints, see write_path): it is probed again, and counted like a wrong hint when it
+    // has appeared — the record is corrected, the hinted order (which skips it) is not used.
+    const bool again = i < n && !bad && rec_slots[i] == kNoSlot;
     unsigned long long m = __ballot(bad);
     if (m && lane == __ffsll((long long)m) - 1) atomicAdd(&flags[2], (uint32_t)__popcll(m));
     while (m) {  // rare: one sub-group probe per mismatching position
@@ -534,6 +538,23 @@ __global__ void __launch_bounds__(256) k_hint_fix(TableDev t, const int64_t* __r
         rec_ids[i0 + l] = key;
         rec_slots[i0 + l] = sl;
       }
+    }
+    // the absent ones (5 % of a batch under churn): eight at a time, one per 8-lane group
+    unsigned long long ma = __ballot(again);
+    const int g = lane >> 3;
+    while (ma) {
+      unsigned long long mm = ma;
+      for (int q = 0; q < g; ++q) mm &= mm - 1;  // group g takes the g-th of the remaining positions
+      const int l = mm ? __ffsll((long long)mm) - 1 : -1;
+      const int64_t key = __shfl(i < n ? ids[i] : kEmpty, l < 0 ? 0 : l);
+      if (l >= 0) {
+        const uint32_t sl = group_find(t, key, sub, gshift);
+        if (sub == 0 && sl != kNoSlot) {
+          rec_slots[i0 + l] = sl;
+          atomicAdd(&flags[2], 1u);
+        }
+      }
+      for (int q = 0; q < 8 && ma; ++q) ma &= ma - 1;
     }
   }
 }
@@ -1932,6 +1953,13 @@ static int read_counters(Table* t, hipStream_t st, int64_t* live, int64_t* tombs
 }
 
 static int hint_drop(Table* t, hipStream_t st);
+static bool keep_hints_enabled() {  // MONO_KEEP_HINTS=0: a gated update drops the queued hints
+  static const bool v = [] {
+    const char* e = getenv("MONO_KEEP_HINTS");
+    return !e || atoi(e) != 0;
+  }();
+  return v;
+}
 static int keys_changed(Table* t, hipStream_t st);
 
 // Rehash into a table of `new_cap` slots (drops tombstones). Peak memory = old + new arrays.
@@ -2716,13 +2744,17 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   if (++t->updates_since_strike >= 64) t->updates_since_strike = t->prep_strikes = 0;
   t->expect_update = pattern && t->prep_strikes < 2;
   if (prepared && !from_keys) return 0;
-  // everything below may insert keys (and move them: rehash): a pending hint is stale, and the
-  // next one waits for what this call enqueues
-  MONO_TRY(hint_drop(t, st));
+  // Everything below may insert keys (and move them: rehash): a pending hint is stale, and the
+  // next one waits for what this call enqueues. The exception is the gated remainder behind a
+  // prepared order: the table has room (no rehash, checked above), an insertion moves no row, and
+  // the only thing a queued hint can have wrong afterwards is an id it recorded as absent —
+  // which k_hint_fix probes again. Those hints stay.
+  const bool keep_hints = prepared && from_keys && keep_hints_enabled();
+  if (!keep_hints) MONO_TRY(hint_drop(t, st));
   struct KeysDone {
-    Table* t; hipStream_t st;
-    ~KeysDone() { (void)keys_changed(t, st); }
-  } keys_done{t, st};
+    Table* t; hipStream_t st; bool on;
+    ~KeysDone() { if (on) (void)keys_changed(t, st); }
+  } keys_done{t, st, !keep_hints};
   if (!prepared) MONO_TRY(ensure_room(t, n, st));
 
   ApplyArgs a{};
