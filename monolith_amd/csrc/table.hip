@@ -160,6 +160,7 @@ struct Table {
     int64_t cap = 0;
   } hints[kHintDepth];
   int hint_head = 0, hint_count = 0;
+  bool hints_kept = false;  // a gated update has kept queued hints: their absent ids get re-probed
   // the streams the update-order chains run on (all Preps share them, alternating: the process
   // has four hardware queues, and the caller's stream and the apply stream take two)
   hipStream_t chain_stream[2] = {nullptr, nullptr};
@@ -2751,6 +2752,7 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   // which k_hint_fix probes again. Those hints stay.
   const bool keep_hints = prepared && from_keys && keep_hints_enabled();
   if (!keep_hints) MONO_TRY(hint_drop(t, st));
+  else t->hints_kept = true;
   struct KeysDone {
     Table* t; hipStream_t st; bool on;
     ~KeysDone() { if (on) (void)keys_changed(t, st); }
@@ -3093,7 +3095,10 @@ static int lookup_impl(Table* t, const int64_t* ids, int64_t n, float* out, hipS
     // steady state the chain finished long ago, beside the update before this lookup.)
     MONO_HIP(hipStreamWaitEvent(st, p.ev_ready, 0));
     p.chain_pending = false;
-    hipLaunchKernelGGL(k_hint_fix, dim3(grid_for(n, 1024, 1024)), dim3(256), 0, st, t->d, ids, n,
+    // (under churn a few per cent of the positions are probed again: one round per wave then,
+    // instead of six — measured: 124 against 145 us, the re-probe itself is what costs)
+    hipLaunchKernelGGL(k_hint_fix, dim3(t->hints_kept ? grid_for(n, 256, 8192) : grid_for(n, 1024, 1024)),
+                       dim3(256), 0, st, t->d, ids, n,
                        t->cache_ids, t->cache_slots, p.d_flags);
     MONO_HIP(hipGetLastError());
     if (out) MONO_TRY(launch_gather(t, t->cache_slots, n, out, aligned, 4096, 8, st));
