@@ -530,8 +530,7 @@ def main_config5(args, device):
 
   # The next lookup is announced one step ahead (a gated update keeps the queued hints: an
   # insertion moves no row, k_hint_fix probes the ids recorded as absent again). One ahead, not
-  # two as on config 2: 471 / 509 / 588 us per step with one / none / two (the re-probe of the
-  # 5 % absent ids makes k_hint_fix the expensive part of a hinted lookup here).
+  # two as on config 2: 471 / 509 / 588 us per step with one / none / two.
   ahead = 0 if args.no_hint else args.c5_hint_ahead
   made = {}  # step -> its ids (made `ahead` steps early when the lookups are announced ahead)
 
