@@ -527,36 +527,31 @@ __global__ void __launch_bounds__(256) k_hint_fix(TableDev t, const int64_t* __r
     // queued hints, see write_path): it is probed again, and counted like a wrong hint when it
     // has appeared — the record is corrected, the hinted order (which skips it) is not used.
     const bool again = i < n && !bad && rec_slots[i] == kNoSlot;
-    unsigned long long m = __ballot(bad);
-    if (m && lane == __ffsll((long long)m) - 1) atomicAdd(&flags[2], (uint32_t)__popcll(m));
-    while (m) {  // rare: one sub-group probe per mismatching position
-      const int l = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int64_t key = __shfl(i < n ? ids[i] : kEmpty, l);
-      // (every 8-lane group probes the same key; group 0's answer is kept)
-      const uint32_t sl = group_find(t, key, sub, gshift);
-      if (lane == 0) {
-        rec_ids[i0 + l] = key;
-        rec_slots[i0 + l] = sl;
-      }
-    }
-    // the absent ones (5 % of a batch under churn): eight at a time, one per 8-lane group
-    unsigned long long ma = __ballot(again);
+    // Both kinds are resolved eight at a time, one position per 8-lane group (a wrong hint makes
+    // EVERY position one of them: probed one after the other that cost 0.45 ms per lookup).
+    const unsigned long long mbad = __ballot(bad);
+    unsigned long long ma = mbad | __ballot(again);
     const int g = lane >> 3;
+    uint32_t changed = 0;  // (wave-uniform)
     while (ma) {
       unsigned long long mm = ma;
       for (int q = 0; q < g; ++q) mm &= mm - 1;  // group g takes the g-th of the remaining positions
       const int l = mm ? __ffsll((long long)mm) - 1 : -1;
       const int64_t key = __shfl(i < n ? ids[i] : kEmpty, l < 0 ? 0 : l);
+      bool chg = false;
       if (l >= 0) {
         const uint32_t sl = group_find(t, key, sub, gshift);
-        if (sub == 0 && sl != kNoSlot) {
-          rec_slots[i0 + l] = sl;
-          atomicAdd(&flags[2], 1u);
+        const bool was_bad = (mbad >> l) & 1ull;
+        if (sub == 0) {
+          if (was_bad) rec_ids[i0 + l] = key;
+          if (was_bad || sl != kNoSlot) rec_slots[i0 + l] = sl;
+          chg = was_bad || sl != kNoSlot;
         }
       }
+      changed += (uint32_t)__popcll(__ballot(chg));
       for (int q = 0; q < 8 && ma; ++q) ma &= ma - 1;
     }
+    if (lane == 0 && changed) atomicAdd(&flags[2], changed);
   }
 }
 
