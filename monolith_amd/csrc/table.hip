@@ -28,6 +28,7 @@
 
 #include "filter_dev.h"
 #include "mono_common.h"
+#include "chain_dev.h"
 
 namespace mono {
 
@@ -184,7 +185,8 @@ struct Table {
   bool ev_k_valid = false;
   // fork / join of the long-segment kernel beside the sub-group kernel
   hipStream_t aux = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
+  Workspace ws_pack;  // packed rows of the long segments (k_long_pack -> k_long_chain)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(256) k_probe(TableDev t, const int64_t* __rest
                                                uint32_t* __restrict__ miss_total) {
   __shared__ uint32_t s_miss;
   if (threadIdx.x == 0) s_miss = 0;
-  if (blockIdx.x == 0 && threadIdx.x < 8) zero8[threadIdx.x] = 0;  // counters of the prepared queues
+  if (blockIdx.x == 0 && threadIdx.x < 16) zero8[threadIdx.x] = 0;  // counters of the prepared queues
   if (blockIdx.x == 0 && threadIdx.x == 8) miss_total[0] = 0;      // k_verify adds this lookup's up
   if (blockIdx.x == 0 && threadIdx.x == 9) miss_total[2] = 0;      // ids that were not the hinted ones
   __syncthreads();
@@ -495,7 +497,7 @@ __global__ void __launch_bounds__(256) k_verify(const int64_t* __restrict__ ids,
                                                 uint32_t* __restrict__ flags,
                                                 uint32_t* __restrict__ handout,
                                                 const uint32_t* __restrict__ blk_miss, int n_blk) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) *handout = 0;  // k_apply_long's queue cursor
+  if (blockIdx.x == 0 && threadIdx.x == 0) handout[0] = handout[1] = 0;  // the long queues' cursors
   if (threadIdx.x == 0) {  // this workgroup's slice of k_probe's per-workgroup miss counts
     const int per = (n_blk + (int)gridDim.x - 1) / (int)gridDim.x;
     uint32_t mc = 0;
@@ -592,7 +594,7 @@ __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t
                                                        uint32_t* __restrict__ zero4) {
   // the apply phase's four queue counters are cleared here: a separate memset costs ~10 us of
   // stream bubble between the sort and k_classify
-  if (zero4 && blockIdx.x == 0 && threadIdx.x < 8) zero4[threadIdx.x] = 0;
+  if (zero4 && blockIdx.x == 0 && threadIdx.x < 16) zero4[threadIdx.x] = 0;
   const int sub = lane_sub(), gshift = lane_gshift();
   const int64_t ngroups = (int64_t)gridDim.x * (blockDim.x / 8);
   for (int64_t i0 = ((int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8) * kIlp; i0 < n;
@@ -642,7 +644,7 @@ __global__ void __launch_bounds__(256) k_claim_pending(TableDev t, const int64_t
                                                        const int64_t* __restrict__ cache_ids,
                                                        const uint32_t* __restrict__ cache_slots,
                                                        int64_t cache_n) {
-  if (zero4 && blockIdx.x == 0 && threadIdx.x < 8) zero4[threadIdx.x] = 0;
+  if (zero4 && blockIdx.x == 0 && threadIdx.x < 16) zero4[threadIdx.x] = 0;
   const int lane = threadIdx.x & 63, sub = lane_sub(), gshift = lane_gshift(), grp = lane >> 3;
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / 64);
   for (int64_t base = ((int64_t)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) * 64; base < n;
@@ -771,7 +773,9 @@ struct ApplyArgs {
   long long global_step;     // Optimize()'s global_step (batch softmax reads it)
   struct LongSeg* queue;     // segments longer than kLongSeg, drained by k_apply_long
   uint32_t* qcount;          // [0] queue entries [1] compacted heads [2] split keys [3] partial rows
-                             // [4] next queue entry to hand out (k_apply_long)
+                             // [4] next queue entry to hand out (k_apply_long / k_long_chain)
+                             // [5] next very long entry to hand out [6] packed blocks
+                             // [8 .. 13] very long entries per length class
   struct SplitSeg* cqueue;   // keys whose segment was cut into chunks, finished by k_combine
   float* partials;           // [partial row][dim] chunk sums of the split keys
   int chunk;                 // occurrences above which a key is split (kChunk)
@@ -796,6 +800,16 @@ struct ApplyArgs {
   uint32_t pk_smask, pk_bmask;
   int pk_sbits, pk_qshift;
   int64_t max_heads;  // the caller's bound on the number of distinct keys (0: n), sizes k_apply's grid
+  // hot-key chains (k_long_pack / k_long_chain): the rows of every long segment are first copied
+  // into `packed` in sorted order, 64-row blocks, four-row groups column-major (chain_dev.h);
+  // blk_src[b] = (sorted position of block b's first row, rows in it). qcount[6] counts blocks.
+  uint2* blk_src;
+  // queue indices of the segments longer than kVeryLong by length class (longest class first,
+  // vl_cap entries each; counts in qcount[8 + class]): each gets a CU to itself
+  uint32_t* vlq;
+  uint32_t vl_cap;
+  float* packed;
+  uint32_t packed_bytes;
 };
 // PTRS: can this instantiation be given per-occurrence source pointers at all? (Only the set-sum
 // mode is; a run-time test in every other kernel's gradient loads cost the headline k_apply a
@@ -816,7 +830,7 @@ struct LongSeg {
   int64_t first, end, key;
   uint32_t slot, fresh;
   uint32_t part;  // partial-row index when this entry is one chunk of a split key, else kNoPart
-  uint32_t pad;
+  uint32_t blk;   // first 64-row block of this entry's packed rows (k_long_pack -> k_long_chain)
 };
 struct SplitSeg {
   int64_t key;
@@ -833,6 +847,12 @@ constexpr int kLongSeg = MONO_LONG_SEG;       // occurrences above which a segme
 // sequential reference (DESIGN.md "hot keys"); MODE_OPT_SEQ is never split.
 constexpr int kChunk = 4096;
 constexpr int kLongMaxDim = 512;   // wider rows stay on the sub-group path
+constexpr int kPackRows = 64;      // rows per packed block = one loop iteration of chain_sum
+constexpr int kVeryLong = 2048;    // occurrences above which a chain gets a CU to itself
+constexpr int kVlClasses = 6;      // ... handed out longest class first
+__host__ __device__ inline int vl_class(int64_t len) {
+  return len > 65536 ? 0 : len > 32768 ? 1 : len > 16384 ? 2 : len > 8192 ? 3 : len > 4096 ? 4 : 5;
+}
 constexpr int kTileFloats = 2048;  // LDS staging tile (8 KB), double buffered
 
 template <typename K>
@@ -1018,11 +1038,18 @@ __device__ __forceinline__ bool long_split(const ApplyArgs& a, int64_t len) {
 __device__ __forceinline__ uint32_t long_parts(const ApplyArgs& a, int64_t len) {
   return long_split(a, len) ? (uint32_t)((len + a.chunk - 1) / a.chunk) : 1u;
 }
+// packed 64-row blocks of a long segment (every part of a split key is padded on its own)
+__device__ __forceinline__ uint32_t long_blocks(const ApplyArgs& a, int64_t len) {
+  const uint32_t nparts = long_parts(a, len);
+  const int64_t csz = (len + nparts - 1) / nparts;
+  const int64_t last = len - (int64_t)(nparts - 1) * csz;
+  return (uint32_t)((nparts - 1) * ((csz + kPackRows - 1) / kPackRows) + (last + kPackRows - 1) / kPackRows);
+}
 // queue entries q .. q + nparts; a split key also takes partial rows pbase .. + nparts and the
-// split-key entry c (all three reserved by the caller)
+// split-key entry c; packed blocks blk .. + long_blocks (all four reserved by the caller)
 __device__ inline void enqueue_long_at(const ApplyArgs& a, int64_t first, int64_t end, int64_t key,
                                        uint32_t slot, uint32_t fresh, uint32_t q, uint32_t pbase,
-                                       uint32_t c) {
+                                       uint32_t c, uint32_t blk) {
   const int64_t len = end - first;
   const bool split = long_split(a, len);
   const uint32_t nparts = long_parts(a, len);
@@ -1038,8 +1065,18 @@ __device__ inline void enqueue_long_at(const ApplyArgs& a, int64_t first, int64_
     ls.end = min(end, ls.first + csz);
     ls.key = key; ls.slot = slot; ls.fresh = fresh;
     ls.part = split ? pbase + p : kNoPart;
-    ls.pad = 0;
+    ls.blk = blk;
     a.queue[q + p] = ls;
+    const int64_t plen = ls.end - ls.first;
+    if (a.blk_src) {
+      for (int64_t r = 0; r < plen; r += kPackRows)
+        a.blk_src[blk++] = make_uint2((uint32_t)(ls.first + r), (uint32_t)min((int64_t)kPackRows, plen - r));
+      if (plen > kVeryLong) {  // (rare: a direct global atomic per entry)
+        const int cl = vl_class(plen);
+        const uint32_t i = atomicAdd(&a.qcount[8 + cl], 1u);
+        if (i < a.vl_cap) a.vlq[(uint32_t)cl * a.vl_cap + i] = q + p;
+      }
+    }
   }
 }
 __device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t end, int64_t key,
@@ -1053,7 +1090,8 @@ __device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t e
     pbase = atomicAdd(&a.qcount[3], nparts);
     c = atomicAdd(&a.qcount[2], 1u);
   }
-  enqueue_long_at(a, first, end, key, slot, fresh, q, pbase, c);
+  const uint32_t blk = a.blk_src ? atomicAdd(&a.qcount[6], long_blocks(a, len)) : 0u;
+  enqueue_long_at(a, first, end, key, slot, fresh, q, pbase, c, blk);
 }
 
 // Write path, step 2: one 8-lane sub-group per distinct key walks that key's occurrences in
@@ -1378,20 +1416,20 @@ constexpr int kClsThreads = 1024;
 constexpr int kClsItems = 4;
 __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow_long,
                                                           uint4* __restrict__ heads) {
-  __shared__ uint32_t s_cnt, s_base, s_lq, s_lp, s_lc, s_lqb, s_lpb, s_lcb;
+  __shared__ uint32_t s_cnt, s_base, s_lq, s_lp, s_lc, s_lb, s_lqb, s_lpb, s_lcb, s_lbb;
   const uint32_t* __restrict__ sk = static_cast<const uint32_t*>(a.skeys);
   const int64_t n = a.n;
   const int tid = threadIdx.x, lane = tid & 63;
   // a sort that failed (look-back time-out) leaves stale ping-pong data behind: emit no heads and
   // no long segments, so that nothing is applied; the host reports the word at its next read-back
   if (a.sort_err && *a.sort_err != 0u) return;
-  if (tid == 0) s_cnt = s_lq = s_lp = s_lc = 0;
+  if (tid == 0) s_cnt = s_lq = s_lp = s_lc = s_lb = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * (kClsThreads * kClsItems);
   uint32_t loc[kClsItems], len[kClsItems], slotv[kClsItems], idxv[kClsItems];
   // long segments: queue entries / partial rows / split-key entries reserved in LDS first, one
   // global atomic per counter and workgroup (a Zipf-heavy batch queues thousands of them)
-  uint32_t lq[kClsItems], lp[kClsItems], lc[kClsItems];
+  uint32_t lq[kClsItems], lp[kClsItems], lc[kClsItems], lb[kClsItems];
   bool sh[kClsItems];
 #pragma unroll
   for (int k = 0; k < kClsItems; ++k) {
@@ -1400,7 +1438,7 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
     len[k] = 1;
     loc[k] = 0;
     lq[k] = kNoPart;
-    lp[k] = lc[k] = 0;
+    lp[k] = lc[k] = lb[k] = 0;
     slotv[k] = idxv[k] = 0;
     if (j < n) {
       const uint32_t slot = sk[j];
@@ -1416,6 +1454,7 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
         if (allow_long && len[k] > (uint32_t)kLongSeg) {
           const uint32_t nparts = long_parts(a, len[k]);
           lq[k] = atomicAdd(&s_lq, nparts);
+          if (a.blk_src) lb[k] = atomicAdd(&s_lb, long_blocks(a, len[k]));
           if (long_split(a, len[k])) {
             lp[k] = atomicAdd(&s_lp, nparts);
             lc[k] = atomicAdd(&s_lc, 1u);
@@ -1439,6 +1478,7 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
   if (tid == 64) s_lqb = s_lq ? atomicAdd(&a.qcount[0], s_lq) : 0u;
   if (tid == 128) s_lpb = s_lp ? atomicAdd(&a.qcount[3], s_lp) : 0u;
   if (tid == 192) s_lcb = s_lc ? atomicAdd(&a.qcount[2], s_lc) : 0u;
+  if (tid == 256) s_lbb = s_lb ? atomicAdd(&a.qcount[6], s_lb) : 0u;
   __syncthreads();
   const uint32_t gb = s_base;
 #pragma unroll
@@ -1446,7 +1486,8 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
     const int64_t j = base + (int64_t)k * kClsThreads + tid;
     if (sh[k]) heads[gb + loc[k]] = make_uint4((uint32_t)j, len[k], slotv[k], idxv[k]);
     if (lq[k] != kNoPart)
-      enqueue_long_at(a, j, j + len[k], 0, slotv[k], 0u, s_lqb + lq[k], s_lpb + lp[k], s_lcb + lc[k]);
+      enqueue_long_at(a, j, j + len[k], 0, slotv[k], 0u, s_lqb + lq[k], s_lpb + lp[k], s_lcb + lc[k],
+                      s_lbb + lb[k]);
   }
 }
 
@@ -1794,6 +1835,196 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
   }
 }
 
+
+// ---- hot-key chains (chain_dev.h) ---------------------------------------------------------------
+// Pack pass: the rows of every long segment are copied, in sorted (= input) order, into 64-row
+// blocks whose four-row groups are column-major — cell (g, e) = rows 4g .. 4g+3 of column e — so
+// that the chain wave reads four rows of its column with one 16-byte LDS load and fetches 1 KiB of
+// consecutive memory per DMA instruction. Rows past a block's count are -0.0f (x + -0.0f == x for
+// every x, signed zeros included). Massively parallel and bandwidth-bound: the one dependent
+// chain per key only starts behind it.
+template <bool PTRS>
+__global__ void __launch_bounds__(256) k_long_pack(TableDev t, ApplyArgs a) {
+  const int D = t.dim;
+  uint32_t nb = a.qcount[6];
+  const uint32_t room = a.packed_bytes / (uint32_t)(kPackRows * D * sizeof(float));
+  if (nb > room) nb = room;  // (the host sizes the scratch for the worst case)
+  const bool vec4 = (D & 3) == 0 && ((a.src_ptrs || a.src_tab) ? a.src_aligned4 != 0
+                                                : (reinterpret_cast<uintptr_t>(a.src) & 15) == 0);
+  const float nz = -0.0f;
+  if (vec4) {
+    // task = (group g, column quad qd): four 16-byte row loads, a 4 x 4 transpose, four cells
+    const int qpr = D / 4, tpb = 16 * qpr;  // quads per row, tasks per block
+    const int bpw = tpb >= 256 ? 1 : 256 / tpb;
+    for (int t0 = threadIdx.x; t0 < bpw * tpb; t0 += 256) {
+      const int tb = t0 / tpb, tt = t0 - tb * tpb;
+      const int g = tt / qpr, qd = tt - g * qpr;
+      for (uint32_t b = blockIdx.x * bpw + tb; b < nb; b += gridDim.x * bpw) {
+        const uint2 bs = a.blk_src[b];
+        float4 r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t rw = 4 * g + i;
+          r[i] = make_float4(nz, nz, nz, nz);
+          if (rw < bs.y)
+            r[i] = *reinterpret_cast<const float4*>(src_row<PTRS>(a, a.sidx[(uint64_t)bs.x + rw], D) + 4 * qd);
+        }
+        float4* dst = reinterpret_cast<float4*>(a.packed + (uint64_t)b * kPackRows * D) + g * D + 4 * qd;
+        dst[0] = make_float4(r[0].x, r[1].x, r[2].x, r[3].x);
+        dst[1] = make_float4(r[0].y, r[1].y, r[2].y, r[3].y);
+        dst[2] = make_float4(r[0].z, r[1].z, r[2].z, r[3].z);
+        dst[3] = make_float4(r[0].w, r[1].w, r[2].w, r[3].w);
+      }
+    }
+  } else {
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+      const uint2 bs = a.blk_src[b];
+      float4* dst = reinterpret_cast<float4*>(a.packed + (uint64_t)b * kPackRows * D);
+      for (int c = threadIdx.x; c < 16 * D; c += 256) {
+        const int g = c / D, e = c - g * D;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t rw = 4 * g + i;
+          v[i] = rw < bs.y ? src_row<PTRS>(a, a.sidx[(uint64_t)bs.x + rw], D)[e] : nz;
+        }
+        dst[c] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+// Ring slots of a chain wave by row width: RV for a very long chain that has its CU to itself,
+// RM for one of AW waves that share a CU (128 KB of LDS either way).
+template <int D> struct ChainCfg;
+template <> struct ChainCfg<8> { static constexpr int RV = 60, RM = 8, AW = 16; };
+template <> struct ChainCfg<16> { static constexpr int RV = 60, RM = 8, AW = 16; };
+template <> struct ChainCfg<32> { static constexpr int RV = 56, RM = 8, AW = 16; };
+template <> struct ChainCfg<64> { static constexpr int RV = 48, RM = 16, AW = 8; };
+constexpr int kChainLds = 128 * 1024;
+
+// one queue entry, start to finish, by one wave: row / state of the key into registers, the
+// chain over its packed rows, then what k_apply_long does at the end of a segment
+template <int OPTK, int MODE, int D, int R>
+__device__ __forceinline__ void chain_entry(const TableDev& t, const ApplyArgs& a, const LongSeg& ls,
+                                            chain_v4i rs, uint32_t ring) {
+  const int e = (int)__lane_id();
+  const bool owner = e < D;
+  const bool part = ls.part != kNoPart;  // one chunk of a split key: emit the chunk sum only
+  float* row = t.rows + (uint64_t)ls.slot * t.row_floats;
+  constexpr int kind = OPTK;
+  const int st0 = D + e, st1 = 2 * D + e;
+  float w = 0.f, s0 = 0.f, s1 = 0.f;
+  OptX ox;
+  ox.gstep = a.global_step;
+  if (owner && !part && MODE != MODE_SET_SUM) {
+    if (ls.fresh) {
+      w = row_init_value(t, ls.key, e);
+      s0 = opt_nstate(kind) >= 1 ? row_init_value(t, ls.key, st0) : 0.f;
+      s1 = opt_nstate(kind) >= 2 ? row_init_value(t, ls.key, st1) : 0.f;
+    } else {
+      w = row[e];
+      if (MODE == MODE_OPT_DEDUP) {
+        s0 = opt_nstate(kind) >= 1 ? row[st0] : 0.f;
+        s1 = opt_nstate(kind) >= 2 ? row[st1] : 0.f;
+      }
+    }
+  }
+  // assign_add adds the rows to the weight one by one; the sums start from the first row
+  // (-0.0f + x == x)
+  const float seed = (MODE == MODE_ASSIGN_ADD && !part) ? w : -0.0f;
+  const uint32_t nblk = (uint32_t)((ls.end - ls.first + kPackRows - 1) / kPackRows);
+  const float acc = chain_sum<D, R>(rs, ls.blk * (uint32_t)(kPackRows * D * sizeof(float)), nblk * (D / 4),
+                                    ring, seed);
+  if (owner && part) {
+    a.partials[(uint64_t)ls.part * D + e] = acc;
+  } else if (owner) {
+    if (MODE == MODE_OPT_DEDUP) opt_step(kind, t.seg[0], a.lr[0], acc, w, s0, s1, ox);
+    else w = acc;
+    row[e] = w;
+    if (MODE != MODE_SET_SUM && (MODE == MODE_OPT_DEDUP || ls.fresh)) {
+      if (opt_nstate(kind) >= 1) row[st0] = s0;
+      if (opt_nstate(kind) >= 2) row[st1] = s1;
+    }
+  }
+  if (e == 0 && !part && t.ts) t.ts[ls.slot] = a.ts;
+}
+template <int OPTK, int MODE, bool VL>
+__device__ __forceinline__ void chain_entry_d(const TableDev& t, const ApplyArgs& a, const LongSeg& ls,
+                                              chain_v4i rs, uint32_t lds0, int w) {
+#define MONO_CHAIN_CASE(DD)                                                                       \
+  case DD:                                                                                        \
+    if (VL) chain_entry<OPTK, MODE, DD, ChainCfg<DD>::RV>(t, a, ls, rs, lds0);                    \
+    else chain_entry<OPTK, MODE, DD, ChainCfg<DD>::RM>(t, a, ls, rs, lds0 + (uint32_t)w * ChainCfg<DD>::RM * 1024u); \
+    break;
+  switch (t.dim) {
+    MONO_CHAIN_CASE(8)
+    MONO_CHAIN_CASE(16)
+    MONO_CHAIN_CASE(32)
+    MONO_CHAIN_CASE(64)
+    default: break;
+  }
+#undef MONO_CHAIN_CASE
+}
+
+// The chains' kernel: workgroups of 16 waves built for 128 VGPRs per lane, so that a workgroup
+// fills the register file of its CU and no other kernel's wave runs beside it. That is the
+// point: beside k_apply's 32 waves a chain wave gets a thirty-third of its CU's memory pipeline
+// (26 ns per row measured, scripts/exp_chain.hip) — alone on the CU it runs at the rate of its
+// instruction stream, 3.4 - 3.6 ns per row with the chip busy or not. A CU under load feeds about
+// one full-rate chain (19 GB/s), so a very long chain (> kVeryLong rows) gets a CU to itself:
+// wave 0 of every workgroup drains that queue first, longest class first, while the other waves
+// wait; then all waves take the remaining entries, one entry per wave.
+template <int OPTK, int MODE>
+__global__ void __launch_bounds__(1024) k_long_chain(TableDev t, ApplyArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char chain_lds[];
+  __shared__ volatile int s_vl_done;
+  const uint32_t nq = a.qcount[0];
+  if (nq == 0) return;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const chain_v4i rs = chain_rsrc(a.packed, a.packed_bytes);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)chain_lds;
+  if (threadIdx.x == 0) s_vl_done = 0;
+  __syncthreads();
+  if (w == 0) {
+    uint32_t cnt[kVlClasses], total = 0;
+#pragma unroll
+    for (int c = 0; c < kVlClasses; ++c) {
+      cnt[c] = min(a.qcount[8 + c], a.vl_cap);
+      total += cnt[c];
+    }
+    for (;;) {
+      uint32_t tk = 0;
+      if (lane == 0) tk = atomicAdd(&a.qcount[5], 1u);
+      tk = __builtin_amdgcn_readfirstlane(tk);
+      if (tk >= total) break;
+      int c = 0;
+#pragma unroll
+      for (int z = 0; z < kVlClasses - 1; ++z)
+        if (c == z && tk >= cnt[z]) { tk -= cnt[z]; c = z + 1; }
+      const LongSeg ls = a.queue[a.vlq[(uint32_t)c * a.vl_cap + tk]];
+      chain_entry_d<OPTK, MODE, true>(t, a, ls, rs, lds0, 0);
+    }
+    if (lane == 0) s_vl_done = 1;
+  } else {
+    while (s_vl_done == 0) __builtin_amdgcn_s_sleep(32);  // (wave 0 always gets there)
+  }
+  int active = 16;
+  if (t.dim == 64) active = ChainCfg<64>::AW;
+  if (w < active) {
+    for (;;) {
+      uint32_t qi = 0;
+      if (lane == 0) qi = atomicAdd(&a.qcount[4], 1u);
+      qi = __builtin_amdgcn_readfirstlane(qi);
+      if (qi >= nq) break;
+      const LongSeg ls = a.queue[qi];
+      if (ls.end - ls.first > kVeryLong) continue;  // (served above)
+      chain_entry_d<OPTK, MODE, false>(t, a, ls, rs, lds0, w);
+    }
+  }
+  __syncthreads();  // the workgroup keeps its CU until its last chain is done
+}
+
 // D1: cuckoo_embedding_hash_table.cc:220-233. One thread per slot, 12 B (key + ts) per slot.
 // The two counters are bumped once per WORKGROUP (counts kept per thread over the grid-stride
 // loop, summed through LDS): an eviction that removes tens of millions of rows otherwise queues
@@ -2070,27 +2301,95 @@ static void launch_long_m(const Table* t, const ApplyArgs& a, unsigned grid, hip
       break;
   }
 }
-static void launch_long_o(const Table* t, const ApplyArgs& a, unsigned grid, hipStream_t st) {
-  const unsigned cgrid = (unsigned)std::min<int64_t>(a.n / a.chunk + 1, 256);
-  const bool may_split = a.mode != MODE_OPT_SEQ && a.n > a.chunk;
-  switch (t->opt_tmpl) {
-    case OPTK_SGD:
-      launch_long_m<OPTK_SGD>(t, a, grid, st);
-      if (may_split) hipLaunchKernelGGL(k_combine<OPTK_SGD>, dim3(cgrid), dim3(64), 0, st, t->d, a);
-      break;
-    case OPTK_ADAGRAD:
-      launch_long_m<OPTK_ADAGRAD>(t, a, grid, st);
-      if (may_split) hipLaunchKernelGGL(k_combine<OPTK_ADAGRAD>, dim3(cgrid), dim3(64), 0, st, t->d, a);
-      break;
-    case OPTK_FTRL:
-      launch_long_m<OPTK_FTRL>(t, a, grid, st);
-      if (may_split) hipLaunchKernelGGL(k_combine<OPTK_FTRL>, dim3(cgrid), dim3(64), 0, st, t->d, a);
-      break;
-    default:
-      launch_long_m<OPTK_MULTI>(t, a, grid, st);
-      if (may_split) hipLaunchKernelGGL(k_combine<OPTK_MULTI>, dim3(cgrid), dim3(64), 0, st, t->d, a);
-      break;
+// Packed 64-row blocks a batch of n occurrences can take: every queue entry (a whole segment or
+// one part of a split key) has more than kLongSeg rows and wastes less than one block.
+static size_t packed_blocks_bound(int64_t n) {
+  return (size_t)n / kPackRows + (size_t)n / kLongSeg + 2;
+}
+// ---- hot-key chains: pack pass + chain kernel (MONO_LONG_CHAIN=0 keeps k_apply_long for everything)
+static bool chain_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("MONO_LONG_CHAIN");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
+static bool chain_ok(const Table* t, int mode) {
+  const int D = t->d.dim;
+  return chain_enabled() && (D == 8 || D == 16 || D == 32 || D == 64) && t->opt_tmpl != OPTK_MULTI &&
+         (mode == MODE_ASSIGN_ADD || mode == MODE_OPT_DEDUP ||
+          (mode == MODE_SET_SUM && t->opt_tmpl == OPTK_SGD));
+}
+// workgroups (= CUs taken) of the chain kernel beside a table's k_apply; the stateless sums have
+// the chip to themselves
+static unsigned chain_wgs(const Table* t) {
+  static const int v = [] {
+    const char* e = getenv("MONO_CHAIN_WGS");
+    return e ? std::max(1, std::min(atoi(e), 256)) : 24;
+  }();
+  return t->d.keys ? (unsigned)v : 256u;
+}
+template <int OPTK, int MODE>
+static int launch_chain_om(const Table* t, const ApplyArgs& a, hipStream_t st) {
+  static bool attr_set = false;  // (one process per GPU)
+  if (!attr_set) {
+    MONO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_long_chain<OPTK, MODE>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, kChainLds));
+    attr_set = true;
   }
+  hipLaunchKernelGGL((k_long_chain<OPTK, MODE>), dim3(chain_wgs(t)), dim3(1024), kChainLds, st, t->d, a);
+  return 0;
+}
+template <int OPTK>
+static int launch_chain_o(const Table* t, const ApplyArgs& a, hipStream_t st) {
+  if (a.mode == MODE_ASSIGN_ADD) return launch_chain_om<OPTK, MODE_ASSIGN_ADD>(t, a, st);
+  return launch_chain_om<OPTK, MODE_OPT_DEDUP>(t, a, st);
+}
+static int launch_pack(const Table* t, const ApplyArgs& a, hipStream_t st) {
+  if (a.src_ptrs || a.src_tab) hipLaunchKernelGGL(k_long_pack<true>, dim3(1024), dim3(256), 0, st, t->d, a);
+  else hipLaunchKernelGGL(k_long_pack<false>, dim3(1024), dim3(256), 0, st, t->d, a);
+  return 0;
+}
+static int launch_chain(const Table* t, const ApplyArgs& a, hipStream_t st) {
+  if (a.mode == MODE_SET_SUM) return launch_chain_om<OPTK_SGD, MODE_SET_SUM>(t, a, st);
+  switch (t->opt_tmpl) {
+    case OPTK_SGD: return launch_chain_o<OPTK_SGD>(t, a, st);
+    case OPTK_ADAGRAD: return launch_chain_o<OPTK_ADAGRAD>(t, a, st);
+    default: return launch_chain_o<OPTK_FTRL>(t, a, st);
+  }
+}
+static void launch_combine(const Table* t, const ApplyArgs& a, hipStream_t st) {
+  const unsigned cgrid = (unsigned)std::min<int64_t>(a.n / a.chunk + 1, 256);
+  if (!(a.mode != MODE_OPT_SEQ && a.n > a.chunk)) return;
+  switch (t->opt_tmpl) {
+    case OPTK_SGD: hipLaunchKernelGGL(k_combine<OPTK_SGD>, dim3(cgrid), dim3(64), 0, st, t->d, a); break;
+    case OPTK_ADAGRAD: hipLaunchKernelGGL(k_combine<OPTK_ADAGRAD>, dim3(cgrid), dim3(64), 0, st, t->d, a); break;
+    case OPTK_FTRL: hipLaunchKernelGGL(k_combine<OPTK_FTRL>, dim3(cgrid), dim3(64), 0, st, t->d, a); break;
+    default: hipLaunchKernelGGL(k_combine<OPTK_MULTI>, dim3(cgrid), dim3(64), 0, st, t->d, a); break;
+  }
+}
+
+// the long segments of a classified batch: pack + chains when the shape allows (a.packed set by
+// launch_apply), k_apply_long otherwise; then the chunk sums of split keys. `after_pack`: an event
+// to record behind the pack pass (the sub-group kernel is started behind it, see launch_apply).
+static int launch_long_o(const Table* t, const ApplyArgs& a, unsigned grid, hipStream_t st,
+                         hipEvent_t after_pack = nullptr) {
+  if (a.packed) {
+    MONO_TRY(launch_pack(t, a, st));
+    if (after_pack) MONO_HIP(hipEventRecord(after_pack, st));
+    MONO_TRY(launch_chain(t, a, st));
+    launch_combine(t, a, st);
+    return 0;
+  }
+  if (after_pack) MONO_HIP(hipEventRecord(after_pack, st));
+  switch (t->opt_tmpl) {
+    case OPTK_SGD: launch_long_m<OPTK_SGD>(t, a, grid, st); break;
+    case OPTK_ADAGRAD: launch_long_m<OPTK_ADAGRAD>(t, a, grid, st); break;
+    case OPTK_FTRL: launch_long_m<OPTK_FTRL>(t, a, grid, st); break;
+    default: launch_long_m<OPTK_MULTI>(t, a, grid, st); break;
+  }
+  launch_combine(t, a, st);
+  return 0;
 }
 static void launch_short(const Table* t, const ApplyArgs& a, hipStream_t st) {
   if (t->opt_tmpl == OPTK_MULTI || t->vec == 1) launch_apply_v<1>(t, a, st);
@@ -2164,6 +2463,18 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
   const bool allow_long = long_allowed(t, a.mode, a.n);
   const unsigned lgrid = (unsigned)std::min<int64_t>(a.n / kLongSeg + 1, 1024);
   double hp = host_prof_on() ? host_now() : 0.0;
+  a.packed = nullptr;
+  a.packed_bytes = 0;
+  if (allow_long && chain_ok(t, a.mode)) {
+    // scratch for the packed rows of the long segments (worst case: every one wastes a block),
+    // + 64 KiB the last chain's ring may read ahead into
+    const size_t need = packed_blocks_bound(a.n) * kPackRows * (size_t)t->d.dim * sizeof(float) + 65536;
+    if (need < 0xFFFF0000ull) {  // (32-bit buffer offsets; beyond that k_apply_long serves)
+      MONO_TRY(t->ws_pack.ensure(need));
+      a.packed = (float*)t->ws_pack.ptr;
+      a.packed_bytes = (uint32_t)need;
+    }
+  }
   if (ready && ready_old) {
     MONO_HIP(hipStreamWaitEvent(st, ready, 0));
     ready = nullptr;
@@ -2172,7 +2483,7 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
   if (a.from_keys) {
     // filter path: the sub-group kernel resolves / gates / claims and feeds the long queue
     launch_short(t, a, st);
-    if (allow_long) launch_long_o(t, a, lgrid, st);
+    if (allow_long) MONO_TRY(launch_long_o(t, a, lgrid, st));
     return 0;
   }
   if (!classified) launch_classify(a, allow_long, heads, st);
@@ -2188,11 +2499,12 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
     MONO_HIP(hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking));
     MONO_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
     MONO_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+    MONO_HIP(hipEventCreateWithFlags(&t->ev_pack, hipEventDisableTiming));
   }
   static const bool serial = getenv("MONO_SERIAL_APPLY") != nullptr;  // profiling aid
   if (serial) {
     if (ready) MONO_HIP(hipStreamWaitEvent(st, ready, 0));
-    launch_long_o(t, a, lgrid, st);
+    MONO_TRY(launch_long_o(t, a, lgrid, st));
     launch_short(t, a, st);
     return 0;
   }
@@ -2205,10 +2517,17 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
   host_tick(a.mode == MODE_SET_SUM ? "gradsum: record fork" : "apply: record fork", &hp);
   if (ready) MONO_HIP(hipStreamWaitEvent(st, ready, 0));
   host_tick(a.mode == MODE_SET_SUM ? "gradsum: wait ready (st)" : "apply: wait ready (st)", &hp);
-  launch_long_o(t, a, lgrid, st);
+  // The chains' workgroups need whole CUs: the sub-group kernel starts behind the pack pass, when
+  // the chain kernel is next in line on its stream, not before (MONO_CHAIN_GATE=0: at the fork).
+  static const bool gate = [] {
+    const char* e = getenv("MONO_CHAIN_GATE");
+    return !e || atoi(e) != 0;
+  }();
+  const bool gated = gate && a.packed != nullptr;
+  MONO_TRY(launch_long_o(t, a, lgrid, st, gated ? t->ev_pack : nullptr));
   host_tick(a.mode == MODE_SET_SUM ? "gradsum: launch long+combine" : "apply: launch long+combine", &hp);
-  MONO_HIP(hipStreamWaitEvent(t->aux, t->ev_fork, 0));
-  if (ready) MONO_HIP(hipStreamWaitEvent(t->aux, ready, 0));
+  MONO_HIP(hipStreamWaitEvent(t->aux, gated ? t->ev_pack : t->ev_fork, 0));
+  if (ready && !gated) MONO_HIP(hipStreamWaitEvent(t->aux, ready, 0));
   host_tick(a.mode == MODE_SET_SUM ? "gradsum: aux waits" : "apply: aux waits", &hp);
   if (t->profile) MONO_HIP(hipEventRecord(t->ev_k[0], t->aux));
   launch_short(t, a, t->aux);
@@ -2229,18 +2548,17 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
 // MONO_EXACT_ORDER=1 (read once per process): no key is ever split, every sum runs strictly in
 // input order at any length — the reference's own order bit for bit, at the price of one
 // dependent chain per hot key (deviation 1).
-static int chunk_size() {  // MONO_CHUNK: experiment knob, clamped to [256, 1 << 20]
+static int chunk_size() {  // MONO_CHUNK=<rows>: sum hot keys in chunks, clamped to [256, 1 << 20]
   static const int v = [] {
-    const char* x = getenv("MONO_EXACT_ORDER");
-    if (x && atoi(x) != 0) return 1 << 30;
     const char* e = getenv("MONO_CHUNK");
-    int c = e ? atoi(e) : kChunk;
-    return std::max(256, std::min(c, 1 << 20));
+    if (!e || atoi(e) <= 0) return 1 << 30;  // default: every sum in the reference's order
+    return std::max(256, std::min(atoi(e), 1 << 20));
   }();
   return v;
 }
 struct QueueLayout {
-  size_t lq, cq, pt, heads;
+  size_t lq, cq, pt, heads, blk, vl;
+  uint32_t vl_cap;
 };
 static QueueLayout queue_layout(int64_t n, int dim) {
   QueueLayout q;
@@ -2250,11 +2568,16 @@ static QueueLayout queue_layout(int64_t n, int dim) {
   q.cq = (((size_t)n / chunk + 2) * sizeof(SplitSeg) + 255) & ~(size_t)255;
   q.pt = (((size_t)n / (chunk / 2) + 2) * (size_t)dim * sizeof(float) + 255) & ~(size_t)255;
   q.heads = n_al * sizeof(uint4);
+  // packed blocks: a segment of len rows takes ceil(len / 64) of them, at most n / 64 + one per
+  // long segment (+ one per extra part of a split key)
+  q.blk = ((packed_blocks_bound(n) + 2) * sizeof(uint2) + 255) & ~(size_t)255;
+  q.vl_cap = (uint32_t)((size_t)n / kVeryLong + 2);
+  q.vl = ((size_t)kVlClasses * q.vl_cap * sizeof(uint32_t) + 255) & ~(size_t)255;
   return q;
 }
 static size_t queue_bytes(int64_t n, int dim) {
   QueueLayout q = queue_layout(n, dim);
-  return 256 + q.lq + q.cq + q.pt + q.heads;
+  return 256 + q.lq + q.cq + q.pt + q.heads + q.blk + q.vl;
 }
 static int queue_setup(ApplyArgs* a, char* q_base, int64_t n, int dim, uint4** heads,
                        hipStream_t st, bool counters_cleared = false) {
@@ -2265,7 +2588,10 @@ static int queue_setup(ApplyArgs* a, char* q_base, int64_t n, int dim, uint4** h
   a->cqueue = (SplitSeg*)(q_base + 256 + q.lq);
   a->partials = (float*)(q_base + 256 + q.lq + q.cq);
   *heads = (uint4*)(q_base + 256 + q.lq + q.cq + q.pt);
-  if (!counters_cleared) MONO_HIP(hipMemsetAsync(a->qcount, 0, 8 * sizeof(uint32_t), st));
+  a->blk_src = (uint2*)(q_base + 256 + q.lq + q.cq + q.pt + q.heads);
+  a->vlq = (uint32_t*)(q_base + 256 + q.lq + q.cq + q.pt + q.heads + q.blk);
+  a->vl_cap = q.vl_cap;
+  if (!counters_cleared) MONO_HIP(hipMemsetAsync(a->qcount, 0, 16 * sizeof(uint32_t), st));
   return 0;
 }
 
@@ -3001,7 +3327,7 @@ int segment_set_sum_planned(const uint32_t* skeys, const uint32_t* sidx, int64_t
   MONO_TRY(queue_setup(&a, q_base, n, D, &heads, st, /*counters_cleared=*/true));
   // the long queue's hand-out cursor restarts (a plan may be applied more than once)
   double hp = host_prof_on() ? host_now() : 0.0;
-  MONO_HIP(hipMemsetAsync(a.qcount + 4, 0, sizeof(uint32_t), st));
+  MONO_HIP(hipMemsetAsync(a.qcount + 4, 0, 2 * sizeof(uint32_t), st));
   host_tick("planned: memset cursor", &hp);
   MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st, /*classified=*/true, ready, /*ready_old=*/true));
   host_tick("planned: launch_apply total", &hp);
@@ -3302,12 +3628,14 @@ int mono_table_destroy(void* table) {
   prep_destroy(t);
   t->ws.release();
   t->ws_gated.release();
+  t->ws_pack.release();
   for (int i = 0; i < 4; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
   for (int i = 0; i < 2; ++i)
     if (t->ev_k[i]) (void)hipEventDestroy(t->ev_k[i]);
   if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
   if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+  if (t->ev_pack) (void)hipEventDestroy(t->ev_pack);
   if (t->aux) (void)hipStreamDestroy(t->aux);
   delete t;
   return 0;

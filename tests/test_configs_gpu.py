@@ -129,9 +129,9 @@ def test_config3_pooling_ftrl_pipeline(B, bag, bag_max, vocab):
       cut += len(feats)
       g_h = et[t_i].grad.detach().cpu().numpy().reshape(-1, D)
       # addends of a gradient row: the id's uses in the batch, once per layout (CONCAT + ADDN).
-      # Rows above 4096 addends (the Zipf heads of the large case) are summed in chunks unless
-      # MONO_EXACT_ORDER=1 (tests/test_layout_gpu.py::test_layout_gradient_exact_order_subprocess
-      # runs this case with it): bounded there, bit-exact everywhere else.
+      # Every row is bit-exact, the Zipf heads of the large case included; only under
+      # MONO_CHUNK=4096 (tests/test_layout_gpu.py::test_layout_gradient_chunked_switch_subprocess
+      # runs this case with it) are rows above 4096 addends summed in chunks and bounded instead.
       uses = np.concatenate([use_count[n] for n in feats]) * 2
       assert_gradient_rows(g_h, g_o, uses, (step, t))
       if not exact_order():

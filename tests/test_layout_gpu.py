@@ -27,16 +27,17 @@ def dev():
 
 
 def exact_order():
-  """MONO_EXACT_ORDER=1 (read once per process by the library): no destination is summed in chunks."""
+  """The default: every sum runs in the reference's order. MONO_CHUNK=<rows> (read once per process
+  by the library) is the switch that sums longer destinations in chunks."""
   import os
-  return os.environ.get("MONO_EXACT_ORDER", "0") not in ("", "0")
+  return os.environ.get("MONO_CHUNK", "0") in ("", "0")
 
 
 def assert_gradient_rows(got, exp, uses, what):
-  """got / exp: [rows, D] gradient rows, uses[r] = addends of row r. Rows of at most 4096 addends
-  are bit-exact; a row with more is summed as near-equal chunks of at most 4096, each in input
-  order (deviation 1): it differs from the sequential sum by reassociation only,
-  bounded here by 2e-5 of the row's magnitude. With MONO_EXACT_ORDER=1 every row is bit-exact."""
+  """got / exp: [rows, D] gradient rows, uses[r] = addends of row r. Every row is bit-exact. Under
+  MONO_CHUNK=4096 (the optional switch) a row with more addends is summed as near-equal chunks of
+  at most 4096, each in input order: it then differs from the sequential sum by reassociation
+  only, bounded here by 2e-5 of the row's magnitude."""
   same = (got.view(np.uint32) == exp.view(np.uint32)).all(axis=1)
   if exact_order():
     assert same.all(), what
@@ -165,25 +166,24 @@ def test_fused_lookup_to_layout_equals_lookup_then_layout(dim, opt, batch, ps_nu
     assert np.array_equal(a.cpu().numpy().view(np.uint32), e.view(np.uint32)), i
 
 
-def test_layout_gradient_exact_order_subprocess():
-  """MONO_EXACT_ORDER=1: destinations with more than 4096 addends are summed strictly in input
-  order as well — the long-chain layout case and config 3's pipeline at its own bag lengths are
-  bit-identical to the oracle, gradients and table state, and so is the 30 000-occurrence key of
-  the dedup update at config 2's shape (the switch is read once per process)."""
+def test_layout_gradient_chunked_switch_subprocess():
+  """MONO_CHUNK=4096 (the optional switch; read once per process): destinations with more than
+  4096 addends are summed in ordered chunks — the long-chain layout cases and config 3's pipeline
+  at its own bag lengths stay within 2e-5 of the row's magnitude of the oracle, every shorter row
+  bit-exact. (The default, tested by every other test of this file, is the reference's order.)"""
   import os
   import subprocess
   import sys
-  env = dict(os.environ, MONO_EXACT_ORDER="1")
+  env = dict(os.environ, MONO_CHUNK="4096")
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
   r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu",
                       os.path.join(root, "tests", "test_layout_gpu.py"),
-                      os.path.join(root, "tests", "test_configs_gpu.py"),
-                      os.path.join(root, "tests", "test_table_gpu.py"), "-k",
-                      "pooling_chain or pooling_hot or b2048_bag50 or hot_key_bound", "--timeout", "120",
+                      os.path.join(root, "tests", "test_configs_gpu.py"), "-k",
+                      "pooling_chain or pooling_hot or b2048_bag50", "--timeout", "120",
                       "--timeout-method", "thread"], env=env, cwd=root, capture_output=True,
                      text=True, timeout=600)
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-  assert "4 passed" in r.stdout, r.stdout[-500:]
+  assert "3 passed" in r.stdout, r.stdout[-500:]
 
 
 def test_layout_gradient_pointer_form_subprocess():
