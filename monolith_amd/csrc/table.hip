@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(256) k_verify(const int64_t* __restrict__ ids,
                                                 uint32_t* __restrict__ flags,
                                                 uint32_t* __restrict__ handout,
                                                 const uint32_t* __restrict__ blk_miss, int n_blk) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) handout[0] = handout[1] = 0;  // the long queues' cursors
+  if (blockIdx.x == 0 && threadIdx.x == 0) handout[0] = handout[1] = handout[2] = 0;  // the long queues' cursors
   if (threadIdx.x == 0) {  // this workgroup's slice of k_probe's per-workgroup miss counts
     const int per = (n_blk + (int)gridDim.x - 1) / (int)gridDim.x;
     uint32_t mc = 0;
@@ -774,7 +774,8 @@ struct ApplyArgs {
   struct LongSeg* queue;     // segments longer than kLongSeg, drained by k_apply_long
   uint32_t* qcount;          // [0] queue entries [1] compacted heads [2] split keys [3] partial rows
                              // [4] next queue entry to hand out (k_apply_long / k_long_chain)
-                             // [5] next very long entry to hand out [6] packed blocks
+                             // [5] next very long entry to hand out [6] chain workgroups that
+                             // have started (k_chain_gate) [7] packed blocks
                              // [8 .. 13] very long entries per length class
   struct SplitSeg* cqueue;   // keys whose segment was cut into chunks, finished by k_combine
   float* partials;           // [partial row][dim] chunk sums of the split keys
@@ -804,6 +805,7 @@ struct ApplyArgs {
   // into `packed` in sorted order, 64-row blocks, four-row groups column-major (chain_dev.h);
   // blk_src[b] = (sorted position of block b's first row, rows in it). qcount[6] counts blocks.
   uint2* blk_src;
+  uint32_t blk_cap;  // entries of blk_src
   // queue indices of the segments longer than kVeryLong by length class (longest class first,
   // vl_cap entries each; counts in qcount[8 + class]): each gets a CU to itself
   uint32_t* vlq;
@@ -1069,8 +1071,9 @@ __device__ inline void enqueue_long_at(const ApplyArgs& a, int64_t first, int64_
     a.queue[q + p] = ls;
     const int64_t plen = ls.end - ls.first;
     if (a.blk_src) {
-      for (int64_t r = 0; r < plen; r += kPackRows)
-        a.blk_src[blk++] = make_uint2((uint32_t)(ls.first + r), (uint32_t)min((int64_t)kPackRows, plen - r));
+      for (int64_t r = 0; r < plen; r += kPackRows, ++blk)
+        if (blk < a.blk_cap)  // (always: the host sizes blk_src for the worst case)
+          a.blk_src[blk] = make_uint2((uint32_t)(ls.first + r), (uint32_t)min((int64_t)kPackRows, plen - r));
       if (plen > kVeryLong) {  // (rare: a direct global atomic per entry)
         const int cl = vl_class(plen);
         const uint32_t i = atomicAdd(&a.qcount[8 + cl], 1u);
@@ -1090,7 +1093,7 @@ __device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t e
     pbase = atomicAdd(&a.qcount[3], nparts);
     c = atomicAdd(&a.qcount[2], 1u);
   }
-  const uint32_t blk = a.blk_src ? atomicAdd(&a.qcount[6], long_blocks(a, len)) : 0u;
+  const uint32_t blk = a.blk_src ? atomicAdd(&a.qcount[7], long_blocks(a, len)) : 0u;
   enqueue_long_at(a, first, end, key, slot, fresh, q, pbase, c, blk);
 }
 
@@ -1478,7 +1481,7 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
   if (tid == 64) s_lqb = s_lq ? atomicAdd(&a.qcount[0], s_lq) : 0u;
   if (tid == 128) s_lpb = s_lp ? atomicAdd(&a.qcount[3], s_lp) : 0u;
   if (tid == 192) s_lcb = s_lc ? atomicAdd(&a.qcount[2], s_lc) : 0u;
-  if (tid == 256) s_lbb = s_lb ? atomicAdd(&a.qcount[6], s_lb) : 0u;
+  if (tid == 256) s_lbb = s_lb ? atomicAdd(&a.qcount[7], s_lb) : 0u;
   __syncthreads();
   const uint32_t gb = s_base;
 #pragma unroll
@@ -1846,9 +1849,10 @@ __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
 template <bool PTRS>
 __global__ void __launch_bounds__(256) k_long_pack(TableDev t, ApplyArgs a) {
   const int D = t.dim;
-  uint32_t nb = a.qcount[6];
-  const uint32_t room = a.packed_bytes / (uint32_t)(kPackRows * D * sizeof(float));
-  if (nb > room) nb = room;  // (the host sizes the scratch for the worst case)
+  // (the block records are read before the block count is known — up to `lim` they are in bounds —
+  // so that the count and the record are one memory level, not two)
+  const uint32_t lim = min(a.blk_cap, a.packed_bytes / (uint32_t)(kPackRows * D * sizeof(float)));
+  const uint32_t* nbp = a.qcount + 7;
   const bool vec4 = (D & 3) == 0 && ((a.src_ptrs || a.src_tab) ? a.src_aligned4 != 0
                                                 : (reinterpret_cast<uintptr_t>(a.src) & 15) == 0);
   const float nz = -0.0f;
@@ -1859,8 +1863,9 @@ __global__ void __launch_bounds__(256) k_long_pack(TableDev t, ApplyArgs a) {
     for (int t0 = threadIdx.x; t0 < bpw * tpb; t0 += 256) {
       const int tb = t0 / tpb, tt = t0 - tb * tpb;
       const int g = tt / qpr, qd = tt - g * qpr;
-      for (uint32_t b = blockIdx.x * bpw + tb; b < nb; b += gridDim.x * bpw) {
+      for (uint32_t b = blockIdx.x * bpw + tb; b < lim; b += gridDim.x * bpw) {
         const uint2 bs = a.blk_src[b];
+        if (b >= *nbp) break;
         float4 r[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -1877,8 +1882,9 @@ __global__ void __launch_bounds__(256) k_long_pack(TableDev t, ApplyArgs a) {
       }
     }
   } else {
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+    for (uint32_t b = blockIdx.x; b < lim; b += gridDim.x) {
       const uint2 bs = a.blk_src[b];
+      if (b >= *nbp) break;
       float4* dst = reinterpret_cast<float4*>(a.packed + (uint64_t)b * kPackRows * D);
       for (int c = threadIdx.x; c < 16 * D; c += 256) {
         const int g = c / D, e = c - g * D;
@@ -1967,6 +1973,19 @@ __device__ __forceinline__ void chain_entry_d(const TableDev& t, const ApplyArgs
 #undef MONO_CHAIN_CASE
 }
 
+// Holds the stream it is launched on until `want` workgroups of the chain kernel have started
+// (or the time is up): the sub-group kernel behind it would otherwise, now and then, fill every
+// CU before the chain workgroups — which need whole CUs — are placed, and the longest chain then
+// runs as the tail of the phase (226 us instead of 115, profiles/r03_c_step_timeline.txt).
+__global__ void __launch_bounds__(64) k_chain_gate(uint32_t* started, uint32_t want, unsigned timeout_us) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    while (atomicAdd(started, 0u) < want &&
+           __builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)timeout_us * 100ull)
+      __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 // The chains' kernel: workgroups of 16 waves built for 128 VGPRs per lane, so that a workgroup
 // fills the register file of its CU and no other kernel's wave runs beside it. That is the
 // point: beside k_apply's 32 waves a chain wave gets a thirty-third of its CU's memory pipeline
@@ -1979,6 +1998,7 @@ template <int OPTK, int MODE>
 __global__ void __launch_bounds__(1024) k_long_chain(TableDev t, ApplyArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char chain_lds[];
   __shared__ volatile int s_vl_done;
+  if (threadIdx.x == 0) atomicAdd(&a.qcount[6], 1u);  // this workgroup has its CU (k_chain_gate)
   const uint32_t nq = a.qcount[0];
   if (nq == 0) return;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -2346,8 +2366,11 @@ static int launch_chain_o(const Table* t, const ApplyArgs& a, hipStream_t st) {
   return launch_chain_om<OPTK, MODE_OPT_DEDUP>(t, a, st);
 }
 static int launch_pack(const Table* t, const ApplyArgs& a, hipStream_t st) {
-  if (a.src_ptrs || a.src_tab) hipLaunchKernelGGL(k_long_pack<true>, dim3(1024), dim3(256), 0, st, t->d, a);
-  else hipLaunchKernelGGL(k_long_pack<false>, dim3(1024), dim3(256), 0, st, t->d, a);
+  // one task per thread where the batch allows (every load of the pass then in flight at once)
+  const int64_t tasks = (int64_t)packed_blocks_bound(a.n) * 4 * t->d.dim;
+  const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>((tasks + 255) / 256, 4096));
+  if (a.src_ptrs || a.src_tab) hipLaunchKernelGGL(k_long_pack<true>, dim3(grid), dim3(256), 0, st, t->d, a);
+  else hipLaunchKernelGGL(k_long_pack<false>, dim3(grid), dim3(256), 0, st, t->d, a);
   return 0;
 }
 static int launch_chain(const Table* t, const ApplyArgs& a, hipStream_t st) {
@@ -2373,10 +2396,12 @@ static void launch_combine(const Table* t, const ApplyArgs& a, hipStream_t st) {
 // launch_apply), k_apply_long otherwise; then the chunk sums of split keys. `after_pack`: an event
 // to record behind the pack pass (the sub-group kernel is started behind it, see launch_apply).
 static int launch_long_o(const Table* t, const ApplyArgs& a, unsigned grid, hipStream_t st,
-                         hipEvent_t after_pack = nullptr) {
+                         hipEvent_t after_pack = nullptr, bool prepacked = false) {
   if (a.packed) {
-    MONO_TRY(launch_pack(t, a, st));
-    if (after_pack) MONO_HIP(hipEventRecord(after_pack, st));
+    if (!prepacked) {
+      MONO_TRY(launch_pack(t, a, st));
+      if (after_pack) MONO_HIP(hipEventRecord(after_pack, st));
+    }
     MONO_TRY(launch_chain(t, a, st));
     launch_combine(t, a, st);
     return 0;
@@ -2452,29 +2477,43 @@ void host_tick(const char* name, double* t0) {
   *t0 = host_now();
 }
 
+static int apply_streams(Table* t) {
+  if (t->aux) return 0;
+  MONO_HIP(hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking));
+  MONO_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+  MONO_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+  MONO_HIP(hipEventCreateWithFlags(&t->ev_pack, hipEventDisableTiming));
+  return 0;
+}
+// Scratch for the packed rows of the long segments (worst case: every one wastes a block), or
+// a.packed = nullptr when this call's long segments go to k_apply_long.
+static int chain_setup(Table* t, ApplyArgs& a, bool allow_long) {
+  a.packed = nullptr;
+  a.packed_bytes = 0;
+  if (!allow_long || !chain_ok(t, a.mode)) return 0;
+  const size_t need = packed_blocks_bound(a.n) * kPackRows * (size_t)t->d.dim * sizeof(float) + 65536;
+  if (need >= 0xFFFF0000ull) return 0;  // (32-bit buffer offsets)
+  MONO_TRY(t->ws_pack.ensure(need));
+  a.packed = (float*)t->ws_pack.ptr;
+  a.packed_bytes = (uint32_t)need;
+  return 0;
+}
+
 // classified: k_classify has already run on these sorted arrays (for this mode's class)
+// prepacked: ... and k_long_pack too (try_prepared launches it ahead of its host round trip;
+// t->ev_pack is recorded behind it)
 // `ready`: an event of another stream the (already classified) input still waits for; both apply
 // streams wait on it directly, so neither start pays a fork behind the other.
 // `ready_old`: the event is most likely over already (a plan made long ago): one wait on the
 // caller's stream ahead of the fork instead of one per apply stream (a cross-stream wait costs
 // 5-17 us of host time each, MONO_HOST_PROF).
 static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, hipStream_t st,
-                        bool classified = false, hipEvent_t ready = nullptr, bool ready_old = false) {
+                        bool classified = false, hipEvent_t ready = nullptr, bool ready_old = false,
+                        bool prepacked = false) {
   const bool allow_long = long_allowed(t, a.mode, a.n);
   const unsigned lgrid = (unsigned)std::min<int64_t>(a.n / kLongSeg + 1, 1024);
   double hp = host_prof_on() ? host_now() : 0.0;
-  a.packed = nullptr;
-  a.packed_bytes = 0;
-  if (allow_long && chain_ok(t, a.mode)) {
-    // scratch for the packed rows of the long segments (worst case: every one wastes a block),
-    // + 64 KiB the last chain's ring may read ahead into
-    const size_t need = packed_blocks_bound(a.n) * kPackRows * (size_t)t->d.dim * sizeof(float) + 65536;
-    if (need < 0xFFFF0000ull) {  // (32-bit buffer offsets; beyond that k_apply_long serves)
-      MONO_TRY(t->ws_pack.ensure(need));
-      a.packed = (float*)t->ws_pack.ptr;
-      a.packed_bytes = (uint32_t)need;
-    }
-  }
+  MONO_TRY(chain_setup(t, a, allow_long));
   if (ready && ready_old) {
     MONO_HIP(hipStreamWaitEvent(st, ready, 0));
     ready = nullptr;
@@ -2495,12 +2534,7 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
     return 0;
   }
   // long segments are latency-bound on a few CUs: run them beside the sub-group kernel
-  if (!t->aux) {
-    MONO_HIP(hipStreamCreateWithFlags(&t->aux, hipStreamNonBlocking));
-    MONO_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
-    MONO_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
-    MONO_HIP(hipEventCreateWithFlags(&t->ev_pack, hipEventDisableTiming));
-  }
+  MONO_TRY(apply_streams(t));
   static const bool serial = getenv("MONO_SERIAL_APPLY") != nullptr;  // profiling aid
   if (serial) {
     if (ready) MONO_HIP(hipStreamWaitEvent(st, ready, 0));
@@ -2524,11 +2558,12 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
     return !e || atoi(e) != 0;
   }();
   const bool gated = gate && a.packed != nullptr;
-  MONO_TRY(launch_long_o(t, a, lgrid, st, gated ? t->ev_pack : nullptr));
+  MONO_TRY(launch_long_o(t, a, lgrid, st, gated ? t->ev_pack : nullptr, prepacked && a.packed));
   host_tick(a.mode == MODE_SET_SUM ? "gradsum: launch long+combine" : "apply: launch long+combine", &hp);
   MONO_HIP(hipStreamWaitEvent(t->aux, gated ? t->ev_pack : t->ev_fork, 0));
   if (ready && !gated) MONO_HIP(hipStreamWaitEvent(t->aux, ready, 0));
   host_tick(a.mode == MODE_SET_SUM ? "gradsum: aux waits" : "apply: aux waits", &hp);
+  if (gated) hipLaunchKernelGGL(k_chain_gate, dim3(1), dim3(64), 0, t->aux, a.qcount + 6, chain_wgs(t), 40u);
   if (t->profile) MONO_HIP(hipEventRecord(t->ev_k[0], t->aux));
   launch_short(t, a, t->aux);
   host_tick(a.mode == MODE_SET_SUM ? "gradsum: launch short" : "apply: launch short", &hp);
@@ -2589,6 +2624,7 @@ static int queue_setup(ApplyArgs* a, char* q_base, int64_t n, int dim, uint4** h
   a->partials = (float*)(q_base + 256 + q.lq + q.cq);
   *heads = (uint4*)(q_base + 256 + q.lq + q.cq + q.pt);
   a->blk_src = (uint2*)(q_base + 256 + q.lq + q.cq + q.pt + q.heads);
+  a->blk_cap = (uint32_t)(q.blk / sizeof(uint2));
   a->vlq = (uint32_t*)(q_base + 256 + q.lq + q.cq + q.pt + q.heads + q.blk);
   a->vl_cap = q.vl_cap;
   if (!counters_cleared) MONO_HIP(hipMemsetAsync(a->qcount, 0, 16 * sizeof(uint32_t), st));
@@ -2823,6 +2859,36 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   host_tick("update: memcpy flags", &hp);
   MONO_HIP(hipEventRecord(p.ev_verify, st));
   host_tick("update: record verify", &hp);
+  // While the host waits for the verdict: the pack pass of the hot keys' rows (it reads the
+  // prepared order and this call's gradients, and writes scratch only, so a "no" costs nothing
+  // but the pass). Only when the prepared classification is this call's and already complete.
+  bool prepacked = false;
+  static const bool prepack_on = [] {
+    const char* e = getenv("MONO_PREPACK");
+    return !e || atoi(e) != 0;
+  }();
+  if (prepack_on && p.mode_class == mode_class(mode) && long_allowed(t, mode, n) && chain_ok(t, mode)) {
+    const bool done = hipEventQuery(p.ev_ready) == hipSuccess;
+    (void)hipGetLastError();
+    if (done) {
+      ApplyArgs pa{};
+      pa.n = n;
+      pa.src = src;
+      pa.mode = mode;
+      pa.skeys = p.sslots;
+      pa.sidx = p.sidx;
+      uint4* heads0 = nullptr;
+      MONO_TRY(queue_setup(&pa, p.q_base, n, t->d.dim, &heads0, st, /*counters_cleared=*/true));
+      MONO_TRY(chain_setup(t, pa, true));
+      if (pa.packed) {
+        MONO_TRY(apply_streams(t));
+        MONO_TRY(launch_pack(t, pa, st));
+        MONO_HIP(hipEventRecord(t->ev_pack, st));
+        prepacked = true;
+      }
+    }
+    host_tick("update: pre-pack", &hp);
+  }
   // (tried twice: the apply kernels launched before the host has the verdict, reading the same
   // flags on the device and doing nothing on "no". Without hints the step is bound by the sort
   // chain and nothing changes (364 against 355 us); with hints the apply starts 20 us earlier and
@@ -2882,7 +2948,8 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   // (prepared classification: its counters stand; k_verify has reset the hand-out cursor)
   MONO_TRY(queue_setup(&a, p.q_base, n, t->d.dim, &heads, st, /*counters_cleared=*/classified));
   MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st, classified,
-                        classified && !t->profile && !slack ? p.ev_ready : nullptr));
+                        classified && !t->profile && !slack ? p.ev_ready : nullptr, false,
+                        prepacked && classified));
   p.chain_pending = false;  // the caller's stream has waited for ev_ready on every path above
   if (!classified) p.mode_class = mode_class(mode);  // the queues now hold this class
   MONO_HIP(hipGetLastError());
@@ -3327,7 +3394,7 @@ int segment_set_sum_planned(const uint32_t* skeys, const uint32_t* sidx, int64_t
   MONO_TRY(queue_setup(&a, q_base, n, D, &heads, st, /*counters_cleared=*/true));
   // the long queue's hand-out cursor restarts (a plan may be applied more than once)
   double hp = host_prof_on() ? host_now() : 0.0;
-  MONO_HIP(hipMemsetAsync(a.qcount + 4, 0, 2 * sizeof(uint32_t), st));
+  MONO_HIP(hipMemsetAsync(a.qcount + 4, 0, 3 * sizeof(uint32_t), st));
   host_tick("planned: memset cursor", &hp);
   MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st, /*classified=*/true, ready, /*ready_old=*/true));
   host_tick("planned: launch_apply total", &hp);
