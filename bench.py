@@ -483,36 +483,58 @@ def cpu_baseline_config3(batch, cfgs, names, D, lr, B, sample=384):
 
 def main_config5(args, device):
   """BASELINE config 5: config 2's stream with a sliding hash filter in front of inserts, 5 % of
-  every step's FIDs from a fresh range, expiry eviction every 24 steps."""
+  every step's FIDs from a fresh range (every fresh FID recurs in five consecutive steps: the
+  filter admits it on its fourth sight, hash_filter.h:157-164), req_time + 1 h per step, every
+  second slot expires after a day, expiry eviction twice inside the timed region."""
   from monolith_amd import _lib, entry, hash_filter_ops, hash_table_ops
   global SLOT_VOCAB
   if args.rows != 1e8:
     scale = args.rows / 1e8
     SLOT_VOCAB = [max(10, int(v * scale)) for v in SLOT_VOCAB]
   total_rows = sum(SLOT_VOCAB)
+  S = len(SLOT_VOCAB)
   lr, D = 0.01, 16
   tc = entry.EmbeddingHashTableConfig(
       segments=[entry.CombineAsSegment(D, entry.RandomUniformInitializer(-0.05, 0.05),
                                        entry.AdagradOptimizer(initial_accumulator_value=0.1))],
       initial_capacity=int(total_rows * 1.15), seed=1234)
   tc.slot_expire_time_config.default_expire_time = 36500
-  tc.slot_expire_time_config.slot_expire_times = {s_: 1 for s_ in range(0, len(SLOT_VOCAB), 2)}
+  tc.slot_expire_time_config.slot_expire_times = {s_: 1 for s_ in range(0, S, 2)}
   thr = entry.SlotOccurrenceThresholdConfig(default_occurrence_threshold=3)
   filt = hash_filter_ops.create_hash_filters(0, True, thr, filter_capacity=300_000_000)[0]
   now0 = 1_700_000_000
-  # populated WITHOUT the filter (a trained table), then the filter is attached
+  # evictions: after the timed steps number ev_every and 2 * ev_every (both inside the timed region
+  # whatever --steps / --warmup are); absolute step indices i1 < i2
+  ev_every = max(1, args.steps // 2)
+  i1, i2 = args.warmup + ev_every - 1, args.warmup + 2 * ev_every - 1
+  # A trained table: populated WITHOUT the filter, last touched "now" — except two classes of rows
+  # of the expiring slots (1 in 256 each) that were last touched almost a day ago: class A is a
+  # day old at the first eviction, class B only at the second.
+  ts_a = now0 - 86400 + 3600
+  ts_b = now0 - 86400 + 3600 * (i1 + 2)
   table = hash_table_ops.hash_table_from_config(entry.HashTableConfigInstance(tc, [lr]),
                                                 hash_filter=filt, name_suffix="bench_c5")
   chunk = 1 << 22
   zeros = torch.zeros((chunk, D), dtype=torch.float32, device=device)
+
+  def touch(ids, ts):
+    _lib.check(_lib.lib.mono_table_assign_add(table.table.h, None, _lib.vp(ids), _lib.vp(zeros),
+                                              C.c_int64(ids.numel()), C.c_int64(ts),
+                                              _lib.stream_ptr(device)))
+
   t0 = time.time()
+  stale = 0
   for s_, v in enumerate(SLOT_VOCAB):
     for lo in range(0, v, chunk):
       m = min(chunk, v - lo)
-      ids = torch.arange(lo, lo + m, device=device, dtype=torch.int64) | (s_ << 48)
-      _lib.check(_lib.lib.mono_table_assign_add(table.table.h, None, _lib.vp(ids), _lib.vp(zeros),
-                                                C.c_int64(m), C.c_int64(now0),
-                                                _lib.stream_ptr(device)))
+      r = torch.arange(lo, lo + m, device=device, dtype=torch.int64)
+      touch(r | (s_ << 48), now0)
+      if s_ % 2 == 0:
+        for cls, ts in ((0, ts_a), (1, ts_b)):
+          old = (r[(r & 255) == cls] | (s_ << 48)).contiguous()
+          if old.numel():
+            touch(old, ts)
+            stale += old.numel()
   torch.cuda.synchronize()
   t_pop = time.time() - t0
   rows0 = table.size()
@@ -524,9 +546,9 @@ def main_config5(args, device):
   n = pool[0].numel()
   grad = torch.randn((n, D), generator=gen, device=device, dtype=torch.float32) * 0.1
   n_fresh = n // 20
+  recur = 5
   fresh_pos = torch.randperm(n, generator=gen, device=device)[:n_fresh]
-  fresh_slot = (fresh_pos % len(SLOT_VOCAB)) << 48
-  state = {"t": table, "fresh": 1 << 40, "evictions": 0}
+  state = {"t": table, "evictions": 0, "evicted_rows": 0, "evict_ms": []}
 
   # The next lookup is announced one step ahead (a gated update keeps the queued hints: an
   # insertion moves no row, k_hint_fix probes the ids recorded as absent again). One ahead, not
@@ -536,15 +558,20 @@ def main_config5(args, device):
 
   def make_ids(i):
     ids = pool[i % n_pool].clone()
-    # 5 % churn: ids nobody has seen (each occurs once this step; the filter counts them)
-    ids[fresh_pos] = fresh_slot | (state["fresh"] + torch.arange(n_fresh, device=device))
-    state["fresh"] += n_fresh // 3  # two thirds of a step's fresh ids come back in later steps
+    # 5 % churn: the fresh FID at position p of step i is (1 << 40) + i * n_fresh / recur + p, so it
+    # comes back in the next four steps (at another position); its slot is a function of the FID
+    x = (1 << 40) + i * (n_fresh // recur) + torch.arange(n_fresh, device=device)
+    ids[fresh_pos] = ((x % S) << 48) | x
     return ids
 
+  ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+  # the input pipeline's work (building the id tensors) is not part of the step: every batch of
+  # the run exists before the clock starts, as on config 2
+  for j in range(args.warmup + args.steps + 8 + ahead + 1):
+    made[j] = make_ids(j)
+  torch.cuda.synchronize()
+
   def step(i):
-    for j in range(i, i + ahead + 1):  # (the input pipeline runs `ahead` batches ahead)
-      if j not in made:
-        made[j] = make_ids(j)
     ids = made.pop(i)
     now = now0 + 3600 * (i + 1)
     t = state["t"]
@@ -552,16 +579,45 @@ def main_config5(args, device):
     for a in range(1, ahead + 1):
       t.lookup_hint(made[i + a], a)
     state["t"] = t.apply_gradients(ids, grad, global_step=i, enable_dedup=True, req_time=now)
-    if i % 24 == 23:
+    if i in (i1, i2):
+      before = state["t"].size()  # (reads a counter back: part of the timed region, twice per run)
+      ev[0].record()
       state["t"].evict(now)
+      ev[1].record()
+      after = state["t"].size()
       state["evictions"] += 1
+      state["evicted_rows"] += before - after
+      state["evict_ms"].append(ev[0].elapsed_time(ev[1]))
 
   dt = _timed_steps(step, args, torch.cuda.synchronize)
   rows1 = state["t"].size()
+  inserted = rows1 - rows0 + state["evicted_rows"]
   uniq = float(np.mean([torch.unique(b).numel() / n for b in pool]))
+  # phases of the steps that follow, each on its own ids (lookup announced as in the timed loop)
   i0 = args.warmup + args.steps
-  ph = _phase_ms([("make_ids", lambda: None), ("step", lambda: step(i0))], reps=8)
-  step_bytes = n * 144 + n * (8 + 4 * D) + uniq * n * (8 + 2 * (8 * D) + 4) + n_fresh * 4
+  reps = 8
+  pe = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+  for r in range(reps):
+    i = i0 + r
+    ids = made.pop(i)
+    pe[r][0].record()
+    state["t"].lookup(ids)
+    pe[r][1].record()
+    for a in range(1, ahead + 1):
+      state["t"].lookup_hint(made[i + a], a)
+    state["t"] = state["t"].apply_gradients(ids, grad, global_step=i, enable_dedup=True,
+                                            req_time=now0 + 3600 * (i + 1))
+    pe[r][2].record()
+  torch.cuda.synchronize()
+  ph = {"lookup": float(np.mean([pe[r][0].elapsed_time(pe[r][1]) for r in range(2, reps)])),
+        "gated apply_gradients": float(np.mean([pe[r][1].elapsed_time(pe[r][2]) for r in range(2, reps)]))}
+  # algorithmic bytes: config 2's step + 2 B read / 2 B written per gated (unknown) id and probed
+  # filter block (two blocks forward); eviction scan 12 B per slot
+  step_bytes = n * 144 + n * (8 + 4 * D) + uniq * n * (8 + 2 * (8 * D) + 4) + n_fresh * 2 * 4
+  cap_slots = 1
+  while cap_slots * 0.6 < total_rows * 1.15:
+    cap_slots *= 2
+  evict_ms = float(np.mean(state["evict_ms"])) if state["evict_ms"] else float("nan")
   res = {
       "metric": "FID lookups+updates/sec (node)", "value": 2.0 * n / dt,
       "unit": "lookups+updates/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -569,23 +625,58 @@ def main_config5(args, device):
       "dtype": "f32", "data": "synthetic",
       "config": {"workload": "config 5: criteo-shaped stream (26 slots, %.3g rows, dim 16, Adagrad, "
                              "batch %d) + sliding hash filter (threshold 3, capacity 3e8, 7 blocks) "
-                             "gating inserts, 5 %% fresh FIDs per step, req_time + 1 h per step, "
-                             "every second slot expires after 1 day, evict every 24 steps%s" %
-                             (total_rows, args.batch,
+                             "gating inserts, 5 %% fresh FIDs per step (each recurs in %d consecutive "
+                             "steps, admitted on its fourth sight), req_time + 1 h per step, every "
+                             "second slot expires after 1 day, expiry eviction after timed steps %d "
+                             "and %d%s" %
+                             (total_rows, args.batch, recur, ev_every, 2 * ev_every,
                               ", the next batch's ids announced by lookup_hint" if ahead else ""),
                  "fids_per_step": n, "unique_ratio": uniq, "fresh_fids_per_step": n_fresh,
-                 "rows_before": rows0, "rows_after": rows1, "evictions": state["evictions"],
+                 "rows_before": rows0, "rows_after": rows1, "stale_rows_planted": stale,
+                 "inserted_rows": inserted, "inserted_per_step": inserted / float(args.warmup + args.steps),
+                 "evictions": state["evictions"], "evicted_rows": state["evicted_rows"],
                  "filter_state": {k: v for k, v in filt.state().items() if k != "num_elements"},
                  "populate_s": t_pop},
       "roofline": {"bound": "hbm", "kernel": "whole step (lookup + gated apply_gradients)",
                    "achieved": step_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": step_bytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
                    "algorithmic_bytes": step_bytes, "phase_ms": ph,
+                   "k_evict_ms": evict_ms, "k_evict_slots": cap_slots,
+                   "k_evict_GBps": cap_slots * 12 / (evict_ms * 1e-3) / 1e9 if evict_ms == evict_ms else None,
+                   "k_evict_frac": (cap_slots * 12 / (evict_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                    if evict_ms == evict_ms else None),
                    "step_algorithmic_GBps": step_bytes / dt / 1e9,
                    "step_frac": step_bytes / dt / 1e9 / HBM_PEAK_GBS},
       "cpu_baseline": None,
   }
+  if not args.no_cpu:
+    res["cpu_baseline"] = cpu_baseline_config5([make_ids(i0 + reps + k) for k in range(2)], pool, grad, lr, D,
+                                               now0)
   emit(res)
+
+
+def cpu_baseline_config5(batches, pool, grad, lr, D, now0):
+  """The oracle ('port', one thread) on two batches of the same stream: a table holding exactly the
+  known FIDs of those batches, the sliding filter (same threshold / capacity / blocks) in front of
+  the inserts; per batch lookup + apply_gradients(dedup, filter)."""
+  from oracle import cpu
+  ids_np = [b.cpu().numpy() for b in batches]
+  g = grad.cpu().numpy()
+  known = np.unique(np.concatenate([b.cpu().numpy() for b in pool]))
+  seg = cpu.seg(D, "adagrad", "uniform", init_a=-0.05, init_b=0.05)
+  t = cpu.OracleTable([seg], initial_capacity=len(known) * 2)
+  t.assign_add(known, np.zeros((len(known), D), np.float32), req_time=now0)
+  f = cpu.OracleFilter("sliding", 300_000_000, 7, 3)
+  t0 = time.perf_counter()
+  for k, ids in enumerate(ids_np):
+    t.lookup(ids)
+    t.apply_gradients(ids, g, [lr], req_time=now0 + 3600 * (k + 1), enable_dedup=True, filt=f)
+  dt = time.perf_counter() - t0
+  n = sum(len(b) for b in ids_np)
+  return {"value": 2.0 * n / dt, "unit": "lookups+updates/s", "cores": 1, "kind": "port",
+          "sample": "%d batches of %d FIDs of the same stream (5 %% fresh), table holding the %d known "
+                    "FIDs, sliding filter threshold 3; lookup + gated apply_gradients(dedup), no "
+                    "eviction" % (len(ids_np), len(ids_np[0]), len(known))}
 
 
 def main():
@@ -735,6 +826,26 @@ def main():
     lk.append(ev0.elapsed_time(ev1))
     ph.append([ms3[0], ms3[1], ms3[2], ka.value])
   _lib.check(_lib.lib.mono_table_profile(h, 0))
+  # ---- the drop-in surface alone (mono_table_lookup + mono_table_apply_gradients, the two calls
+  # the reference's HashTable has): the same steps with no lookup announced ahead, timed the same
+  # way after the queued hints have run out
+  no_hint_ms = None
+  if not args.no_hint:
+    def step_plain(i):
+      ids = pool[i % n_pool]
+      _lib.check(_lib.lib.mono_table_lookup(h, _lib.vp(ids), C.c_int64(n), _lib.vp(out), sp))
+      _lib.check(_lib.lib.mono_table_apply_gradients(h, None, _lib.vp(ids), _lib.vp(grad),
+                                                     C.c_int64(n), lrs, C.c_int(1), C.c_int64(10 + i),
+                                                     C.c_int64(i), C.c_int(1), sp))
+    base_i = args.warmup + args.steps + 10
+    for i in range(6):
+      step_plain(base_i + i)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+      step_plain(base_i + 6 + i)
+    torch.cuda.synchronize()
+    no_hint_ms = (time.perf_counter() - t1) / args.steps * 1e3
   lk_ms = float(np.mean(lk[2:]))
   find_ms, sort_ms, apply_ms, kapply_ms = [float(x) for x in np.mean(np.array(ph[2:]), axis=0)]
   # occurrences / keys that k_apply_long serves instead (segments longer than 96, table.hip kLongSeg)
@@ -778,7 +889,7 @@ def main():
   traffic, traffic_src = None, None
   try:
     import glob
-    pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_*_pmc_summary.json")))[-1]
+    pmc_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[0-9]_*_pmc_summary.json")))[-1]
     with open(pmc_file) as f:
       pmc = json.load(f)["kernels"]
     members = (["mono::k_apply<2, 1, 3>"] if kapply_ms == kapply_ms else
@@ -814,6 +925,14 @@ def main():
                    "long_segment_occurrences": n_long, "long_segment_keys": u_long,
                    "measured_random_access_ceiling": measured_ceiling(),
                    "kernel_ms": {k: v[0] for k, v in kern.items()},
+                   "summation_order": "every key's gradients in input order, the reference's "
+                                      "(bridge :241-266), at any number of occurrences; "
+                                      "MONO_CHUNK=<rows> is the opt-in chunked sum",
+                   "no_hint_ms_per_step": no_hint_ms,
+                   "no_hint_value": (2.0 * n / (no_hint_ms * 1e-3)) if no_hint_ms else None,
+                   "no_hint_note": "the same step through the reference's own two calls only "
+                                   "(mono_table_lookup, mono_table_apply_gradients), measured in this "
+                                   "run after the timed region",
                    "step_algorithmic_GBps": step_gbs, "step_frac": step_gbs / HBM_PEAK_GBS},
   }
   if rank == 0 and world == 1 and not args.no_cpu:

@@ -88,6 +88,13 @@ typedef struct {
   const int32_t* slot_ids;           /* host pointer */
   const int32_t* slot_expire_days;   /* host pointer */
   uint64_t seed;                     /* seed of the random_uniform initializer */
+  /* ABI version 5. embedding_hash_table.proto:84-86 / embedding_hash_table_tf_bridge.cc:69-100:
+   * every feature_evict_every_n_hours of WALL CLOCK the table evicts with the largest req_time it
+   * has seen (mono_table_evict(table, max_update_ts)). The reference does it from a thread of the
+   * bridge that polls every 10 s; here the check runs at the entry of every write call (assign /
+   * assign_add / apply_gradients), on that call's stream, i.e. between two calls like the thread. */
+  int32_t enable_feature_eviction;
+  int32_t feature_evict_every_n_hours;
 } mono_table_cfg;
 
 const char* mono_last_error(void);
@@ -206,6 +213,11 @@ int mono_table_clear(void* table, void* stream);
 int mono_table_evict(void* table, int64_t max_update_time, void* stream);
 /* EmbeddingHashTableTfBridge::max_update_ts_sec (bridge :377-379). */
 int mono_table_max_update_ts(void* table, int64_t* h_out);
+/* The clock of the periodic eviction (enable_feature_eviction): now_sec >= 0 replaces the wall
+ * clock (std::chrono::system_clock in the bridge, :74-78) until it is set again, -1 gives it
+ * back. For tests and for replaying a log at its own pace; h_evictions (may be NULL) receives
+ * the number of periodic evictions the table has run so far. */
+int mono_table_set_clock(void* table, int64_t now_sec, int64_t* h_evictions);
 /* Make room for `rows` live rows without a rehash inside a later call (the cuckoo map's
  * reserve(): cuckoohash_map.hpp:131); may reallocate + rehash; synchronises. */
 int mono_table_reserve(void* table, int64_t rows, void* stream);
@@ -326,7 +338,8 @@ int mono_reduce_sum(const int64_t* row_ids, const float* values, int64_t n, int6
 int mono_reduce_mean(const int64_t* row_ids, const float* values, int64_t n, int64_t dim,
                      int64_t batch, float* out, void* stream);
 /* No counterpart in the reference: mono_reduce_sum for callers that cannot allocate device memory
- * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc). Same
+ * (tight serving loops, harnesses that forbid hipMalloc; NOT for use under HIP graph capture: like
+ * mono_reduce_sum it reads a flag word back and synchronises the stream). Same
  * arguments, same result, same errors; its scratch (sortedness flag, (row, position) pairs, radix
  * sort temporaries) is a fixed 16 MiB __device__ array of the library, one copy per GPU, so the
  * call never calls hipMalloc / hipFree or any allocating routine. Limits: n <= 524288 row ids per

@@ -32,7 +32,8 @@ class TableCfg(C.Structure):  # mono_table_cfg
               ("segments", C.POINTER(SegCfg)), ("initial_capacity", C.c_int64),
               ("n_slot_expire", C.c_int32), ("entry_type", C.c_int32),
               ("slot_ids", C.POINTER(C.c_int32)), ("slot_expire_days", C.POINTER(C.c_int32)),
-              ("seed", C.c_uint64)]
+              ("seed", C.c_uint64), ("enable_feature_eviction", C.c_int32),
+              ("feature_evict_every_n_hours", C.c_int32)]
 
 
 def _load():

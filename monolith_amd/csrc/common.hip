@@ -121,7 +121,7 @@ static uint32_t masked_crc(const uint8_t* p, size_t n) {
 
 extern "C" {
 const char* mono_last_error(void) { return mono::last_error_ref().c_str(); }
-int mono_abi_version(void) { return 4; }
+int mono_abi_version(void) { return 5; }
 
 uint32_t mono_crc32c(const void* data, int64_t n) { return mono::crc32c((const uint8_t*)data, (size_t)n); }
 

@@ -48,6 +48,9 @@ struct GradPlan {
   int64_t covered = 0;  // floats [0, covered) each belong to the row of some occurrence
   Workspace ws;
   hipEvent_t ready = nullptr;
+  // behind the last gradient that read this plan (another stream than the one that rebuilds it)
+  hipEvent_t consumed = nullptr;
+  bool consumed_set = false;
 };
 static GradPlan g_plans[2];
 static uint64_t g_plan_seq = 0;
@@ -119,6 +122,11 @@ static int grad_plan_build(const std::vector<int32_t*>& offs, const int64_t* h_l
   void* tmp = base + bytes;
   MONO_HIP(hipEventRecord(g_plan_src, st));
   MONO_HIP(hipStreamWaitEvent(g_plan_stream, g_plan_src, 0));
+  // the slot is recycled: the gradient that used the plan two reorders back may still be reading it
+  if (p.consumed_set) {
+    MONO_HIP(hipStreamWaitEvent(g_plan_stream, p.consumed, 0));
+    p.consumed_set = false;
+  }
   for (int m = 0; m < M; ++m) {
     if (h_lens[m] == 0) continue;
     uint32_t* skey = (uint32_t*)(base + p.o_skey[m]);
@@ -695,18 +703,22 @@ int mono_reduce_sum_noalloc(const int64_t* row_ids, const float* values, int64_t
   // written before it is read.
   int h_flags = 0;
   MONO_HIP(hipMemsetAsync(flags, 0, sizeof(int), st));
-  if (n > 0)
+  if (n > 0) {
     hipLaunchKernelGGL(k_check_sorted<int64_t>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st,
                        row_ids, n, batch, flags);
+    MONO_HIP(hipGetLastError());
+  }
   MONO_HIP(hipMemcpyAsync(&h_flags, flags, sizeof(int), hipMemcpyDeviceToHost, st));
   MONO_HIP(hipStreamSynchronize(st));
   MONO_REQUIRE(!(h_flags & 2), "mono_reduce_sum_noalloc: a row id is outside [0, %lld)", (long long)batch);
   SortedRows<int64_t> sr;
-  if (!(h_flags & 1)) {
+  const bool sorted_here = (h_flags & 1) != 0;
+  if (!sorted_here) {
     sr.rows = row_ids;
   } else {
     hipLaunchKernelGGL(k_keys_to_u32<int64_t>, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, row_ids,
                        n, kin, iin);
+    MONO_HIP(hipGetLastError());
     MONO_TRY(sort_pairs_u32(kin, kout, iin, iout, (size_t)n, end_bit, base + off_tmp, tmp_bytes, st));
     sr.urows = kout;
     sr.perm = iout;
@@ -714,6 +726,16 @@ int mono_reduce_sum_noalloc(const int64_t* row_ids, const float* values, int64_t
   hipLaunchKernelGGL((k_segment_reduce<int64_t, false>), dim3(grid_for(batch * dim, 256)), dim3(256),
                      0, st, sr, values, n, dim, batch, single_split(out, dim));
   MONO_HIP(hipGetLastError());
+  if (sorted_here) {
+    // the fused sort passes give up (and say so in a sticky word) rather than wait forever for a
+    // look-back word: sums over a half-sorted order must not be handed out as a result
+    uint32_t h_err = 0;
+    if (uint32_t* w = sort_error_word()) {
+      MONO_HIP(hipMemcpyAsync(&h_err, w, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      MONO_HIP(hipStreamSynchronize(st));
+      MONO_TRY(sort_error_report(h_err));
+    }
+  }
   return 0;
 }
 
@@ -872,6 +894,9 @@ static int gather_gradient(int64_t plan_token, int64_t fused_len, const float* c
                                        (const uint32_t*)(base + plan->o_sidx[m]), h_lens[m], grads[m],
                                        h_dims[m], aligned4, out, base + plan->o_q[m], plan->ready, st));
     }
+    if (!plan->consumed) MONO_HIP(hipEventCreateWithFlags(&plan->consumed, hipEventDisableTiming));
+    MONO_HIP(hipEventRecord(plan->consumed, st));
+    plan->consumed_set = true;
     host_tick("grad: planned sums (all slots)", &hp);
     return 0;
   }
@@ -929,6 +954,12 @@ struct ReorderPending {
 };
 static ReorderPending g_reorder;
 static Workspace g_ws_reorder, g_ws_reorder_sort;
+// Behind the last kernel of the previous reorder (its offsets pass and the plan of its gradient run
+// on after the sizes event that finish() waits for): a begin on ANOTHER stream waits for it before
+// it overwrites the shared scratch (dedup cells, slot table, sort scratch).
+static hipEvent_t g_ev_tail = nullptr;
+static hipStream_t g_tail_stream = nullptr;
+static bool g_tail_set = false;
 
 static int reorder_begin(const int64_t* const* inputs, const int64_t* h_lens, int M, int N,
                          const int32_t* h_dims, int shard_rule, int64_t* out_ids,
@@ -981,6 +1012,7 @@ static int reorder_begin(const int64_t* const* inputs, const int64_t* h_lens, in
   const size_t off_scan = off_dims + t_al * 4;
   const size_t off_hist = off_scan + t_al * 4;
   bytes = off_hist + hist_al * 4;
+  if (g_tail_set && g_tail_stream != st) MONO_HIP(hipStreamWaitEvent(st, g_ev_tail, 0));
   MONO_TRY(g_ws_reorder.ensure(bytes));
   char* base = (char*)g_ws_reorder.ptr;
   SlotMeta* d_sm = (SlotMeta*)(base + off_meta);
@@ -1039,6 +1071,10 @@ static int reorder_begin(const int64_t* const* inputs, const int64_t* h_lens, in
     MONO_TRY(grad_plan_build(offs, h_lens, h_dims, M, total, st, &g_reorder.plan));
   }
   host_tick("reorder: plan build launches", &hp);
+  if (!g_ev_tail) MONO_HIP(hipEventCreateWithFlags(&g_ev_tail, hipEventDisableTiming));
+  MONO_HIP(hipEventRecord(g_ev_tail, st));
+  g_tail_stream = st;
+  g_tail_set = true;
   g_reorder.pin = pin;
   g_reorder.active = true;
   return 0;

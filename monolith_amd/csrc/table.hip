@@ -175,6 +175,9 @@ struct Table {
   int updates_since_strike = 0;
   int last_mode_class = 1;
   int64_t max_update_ts = 0;
+  // periodic eviction (bridge :69-100): every evict_every_sec of wall clock, checked at the entry
+  // of a write call; -1 = off. test_clock >= 0 stands in for the wall clock.
+  int64_t evict_every_sec = -1, last_evict_wall = 0, test_clock = -1, periodic_evictions = 0;
   int32_t* slot_expire_dev = nullptr;
   Workspace ws;
   Workspace ws_gated;  // the gated remainder of a write call with a hash filter
@@ -514,7 +517,7 @@ __global__ void __launch_bounds__(256) k_verify(const int64_t* __restrict__ ids,
 
 // A lookup that consumes a hint: positions whose id is not the hinted one are resolved now and
 // the record corrected (so the rows gathered next are the right ones whatever was hinted);
-// flags[2] counts them, and the hinted update order is only used when there were none.
+// flags[2] says there were some, and the hinted update order is only used when there were none.
 __global__ void __launch_bounds__(256) k_hint_fix(TableDev t, const int64_t* __restrict__ ids, int64_t n,
                                                   int64_t* __restrict__ rec_ids,
                                                   uint32_t* __restrict__ rec_slots,
@@ -553,7 +556,10 @@ __global__ void __launch_bounds__(256) k_hint_fix(TableDev t, const int64_t* __r
       changed += (uint32_t)__popcll(__ballot(chg));
       for (int q = 0; q < 8 && ma; ++q) ma &= ma - 1;
     }
-    if (lane == 0 && changed) atomicAdd(&flags[2], changed);
+    // (a flag, not a count: with a hash filter ~1 % of a batch is inserted per step, and that many
+    // atomics on one word — ~90 retire per microsecond — made this kernel 150 us; the load keeps
+    // the stores to a handful per L2)
+    if (lane == 0 && changed && __builtin_nontemporal_load(&flags[2]) == 0u) flags[2] = 1u;
   }
 }
 
@@ -2563,7 +2569,9 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
   MONO_HIP(hipStreamWaitEvent(t->aux, gated ? t->ev_pack : t->ev_fork, 0));
   if (ready && !gated) MONO_HIP(hipStreamWaitEvent(t->aux, ready, 0));
   host_tick(a.mode == MODE_SET_SUM ? "gradsum: aux waits" : "apply: aux waits", &hp);
-  if (gated) hipLaunchKernelGGL(k_chain_gate, dim3(1), dim3(64), 0, t->aux, a.qcount + 6, chain_wgs(t), 40u);
+  // (the stateless sums launch one chain workgroup per CU: nothing to keep the sub-group kernel from)
+  if (gated && t->d.keys)
+    hipLaunchKernelGGL(k_chain_gate, dim3(1), dim3(64), 0, t->aux, a.qcount + 6, chain_wgs(t), 40u);
   if (t->profile) MONO_HIP(hipEventRecord(t->ev_k[0], t->aux));
   launch_short(t, a, t->aux);
   host_tick(a.mode == MODE_SET_SUM ? "gradsum: launch short" : "apply: launch short", &hp);
@@ -3643,6 +3651,7 @@ int mono_table_create(const mono_table_cfg* cfg, void** out_table) {
   }
   d.row_floats = st;
   d.seed = cfg->seed;
+  if (cfg->enable_feature_eviction) t->evict_every_sec = (int64_t)cfg->feature_evict_every_n_hours * 3600;
   d.default_expire_days = cfg->default_expire_days;
   // the three reference-config optimizers have specialised kernels; the rest (and mixes) take
   // the generic per-element path
@@ -3757,10 +3766,36 @@ int mono_table_lookup_hint(void* table, const int64_t* ids, int64_t n, int ahead
   return lookup_hint((Table*)table, ids, n, ahead, (hipStream_t)stream);
 }
 
+// embedding_hash_table_tf_bridge.cc:69-100. The bridge's thread looks every 10 s; the first look
+// only notes the time, later ones evict once feature_evict_every_n_hours have passed since the last
+// eviction (or since that first look), with the largest req_time seen so far. Here the look happens
+// at the entry of a write call — between two calls, where the thread's would fall as well.
+static int periodic_evict(Table* t, void* stream) {
+  if (t->evict_every_sec < 0) return 0;
+  const int64_t now = t->test_clock >= 0 ? t->test_clock : (int64_t)time(nullptr);
+  if (t->last_evict_wall == 0) {
+    t->last_evict_wall = now;
+    return 0;
+  }
+  if (now - t->last_evict_wall < t->evict_every_sec) return 0;
+  t->last_evict_wall = now;
+  ++t->periodic_evictions;
+  return mono_table_evict(t, t->max_update_ts, stream);
+}
+
+int mono_table_set_clock(void* table, int64_t now_sec, int64_t* h_evictions) {
+  MONO_REQUIRE(table, "mono_table_set_clock: null table");
+  Table* t = (Table*)table;
+  t->test_clock = now_sec >= 0 ? now_sec : -1;
+  if (h_evictions) *h_evictions = t->periodic_evictions;
+  return 0;
+}
+
 int mono_table_assign(void* table, void* filter, const int64_t* ids, const float* values, int64_t n,
                       int64_t req_time, void* stream) {
   MONO_REQUIRE(table, "mono_table_assign: null table");
   Table* t = (Table*)table;
+  MONO_TRY(periodic_evict(t, stream));
   t->max_update_ts = std::max(t->max_update_ts, req_time);
   return write_path(t, filter, ids, values, nullptr, n, MODE_ASSIGN, nullptr, 0, req_time, 0,
                     (hipStream_t)stream);
@@ -3770,6 +3805,7 @@ int mono_table_assign_add(void* table, void* filter, const int64_t* ids, const f
                           int64_t n, int64_t req_time, void* stream) {
   MONO_REQUIRE(table, "mono_table_assign_add: null table");
   Table* t = (Table*)table;
+  MONO_TRY(periodic_evict(t, stream));
   if (n > 0) t->max_update_ts = std::max(t->max_update_ts, req_time);
   return write_path(t, filter, ids, values, nullptr, n, MODE_ASSIGN_ADD, nullptr, 0, req_time, 1,
                     (hipStream_t)stream);
@@ -3788,6 +3824,7 @@ int mono_table_apply_gradients(void* table, void* filter, const int64_t* ids, co
   MONO_REQUIRE(n_learning_rates == t->d.n_seg,
                "mono_table_apply_gradients: %d learning rates for %d segments", n_learning_rates,
                t->d.n_seg);
+  MONO_TRY(periodic_evict(t, stream));
   t->max_update_ts = std::max(t->max_update_ts, req_time);
   return write_path(t, filter, ids, grads, nullptr, n, enable_dedup ? MODE_OPT_DEDUP : MODE_OPT_SEQ,
                     h_learning_rates, n_learning_rates, req_time, 0, (hipStream_t)stream,

@@ -118,6 +118,11 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
       all_fids, shard_sizes, sharded_slot_sizes, fused_embedding_offsets = \
           early_reorder_indicies_res_pack
     else:
+      # (a reorder started ahead and never asked for would leave the library waiting for its
+      # finish: retire it before this batch's own)
+      stale, self._prefetched = self._prefetched, None
+      if stale is not None and hasattr(stale, "result"):
+        stale.result()
       all_fids, shard_sizes, sharded_slot_sizes, fused_embedding_offsets = \
           self._ops.fused_reorder_by_indices(sorted_input, self._shard_num, self._output_dims)
 
@@ -217,6 +222,12 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
     if next_slot_to_id is not None:
       if self._side_stream is None:
         self._side_stream = torch.cuda.Stream(grad_flat.device)
+      # the next batch's ids may come out of work on the current stream (an H2D copy, id
+      # preprocessing): the side stream starts behind it, and the tensors stay alive for it
+      self._side_stream.wait_stream(torch.cuda.current_stream(grad_flat.device))
+      for v in next_slot_to_id.values():
+        if isinstance(v, torch.Tensor) and v.is_cuda:
+          v.record_stream(self._side_stream)
       with torch.cuda.stream(self._side_stream):
         prefetched = self.reorder_begin(next_slot_to_id)
 

@@ -136,7 +136,9 @@ class _TableResource:
     dd = (C.c_int32 * max(n, 1))(*list(se.values()))
     cfg = _lib.TableCfg(len(segs), table_config.slot_expire_time_config.default_expire_time, arr,
                         table_config.initial_capacity, n,
-                        2 if table_config.entry_type == "serving" else 0, sl, dd, table_config.seed)
+                        2 if table_config.entry_type == "serving" else 0, sl, dd, table_config.seed,
+                        1 if table_config.enable_feature_eviction else 0,
+                        int(table_config.feature_evict_every_n_hours))
     self.serving = table_config.entry_type == "serving"
     self.h = C.c_void_p()
     self.filter = hash_filter

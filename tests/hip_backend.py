@@ -75,6 +75,9 @@ def table_config(cfg):
   tc.slot_expire_time_config.default_expire_time = cfg.get("default_expire_days", 36500)
   tc.slot_expire_time_config.slot_expire_times = {
       int(k): v for k, v in cfg.get("slot_expire", {}).items()}
+  if "evict_every_n_hours" in cfg:  # CuckooHashTableConfig(feature_evict_every_n_hours=...)
+    tc.enable_feature_eviction = True
+    tc.feature_evict_every_n_hours = cfg["evict_every_n_hours"]
   return tc
 
 

@@ -199,6 +199,58 @@ def test_evict_and_save_time_expiry():
   _assert_same_state(o, h)
 
 
+def test_periodic_eviction_with_injected_clock():
+  """enable_feature_eviction / feature_evict_every_n_hours (embedding_hash_table.proto:84-86): the
+  bridge evicts with the largest req_time seen so far every N hours of WALL clock
+  (embedding_hash_table_tf_bridge.cc:69-100: the first look only notes the time; a later look
+  evicts once N hours have passed since the last eviction and notes the time again). The library
+  looks at the entry of every write call; with the clock injected (mono_table_set_clock) the
+  evictions fall exactly where the rule below puts them, and the table equals the oracle driven
+  by the same rule — rows, timestamps, survivors."""
+  import ctypes as C
+  from monolith_amd import _lib
+  cfg = {"segments": [{"dim": 4, "opt": "adagrad"}], "default_expire_days": 2,
+         "slot_expire": {"1": 1, "3": 100}, "evict_every_n_hours": 6}
+  o, h, _, _ = _pair(cfg)
+  rng = np.random.Generator(np.random.PCG64(17))
+  wall0, last, n_evict = 1_700_000_000, 0, 0
+  count = C.c_int64()
+  for step in range(40):
+    wall = wall0 + step * 2 * 3600 + (step % 3) * 1000      # the host's clock: ~2 h per call
+    req = 86400 * step // 3                                 # the data's clock: 8 h per call
+    _lib.check(_lib.lib.mono_table_set_clock(h.t.table.h, C.c_int64(wall), None))
+    # the reference's rule, restated: look BEFORE the call is applied
+    if last == 0:
+      last = wall
+    elif wall - last >= 6 * 3600:
+      o.evict(o.max_update_ts())
+      last = wall
+      n_evict += 1
+    slots = rng.integers(0, 5, 2000)
+    ids = ((slots.astype(np.int64) << 48) | rng.integers(0, 3000, 2000)).astype(np.int64)
+    g = rng.normal(0, 1, (2000, 4)).astype(np.float32)
+    kind = step % 3
+    for t in (o, h):
+      if kind == 0:
+        t.apply_gradients(ids, g, [0.05], req_time=req, enable_dedup=True)
+      elif kind == 1:
+        t.assign_add(ids, g, req_time=req)
+      else:
+        t.assign(ids[:500], g[:500], req_time=req)
+    if step % 5 == 4:
+      _assert_same_state(o, h)
+  _lib.check(_lib.lib.mono_table_set_clock(h.t.table.h, C.c_int64(-1), C.byref(count)))
+  assert count.value == n_evict and n_evict >= 10, (count.value, n_evict)
+  _assert_same_state(o, h)
+  assert o.size() < 15000  # (rows did leave)
+  # a table without the flag never evicts by itself
+  o2, h2, _, _ = _pair({"segments": [{"dim": 4, "opt": "adagrad"}], "default_expire_days": 0})
+  for t in (o2, h2):
+    t.assign_add(np.arange(10, dtype=np.int64), np.ones((10, 4), np.float32), req_time=5)
+    t.assign_add(np.arange(10, dtype=np.int64), np.ones((10, 4), np.float32), req_time=9 * 86400)
+  assert h2.size() == 10 and o2.size() == 10
+
+
 def test_save_restore_roundtrip():
   """hash_table_restore_op.cc:82-131: clear + upsert of (id, row incl. optimizer state, ts)."""
   o, h, _, _ = _pair(CFGS["ftrl16"])
