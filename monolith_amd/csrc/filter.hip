@@ -134,22 +134,17 @@ __global__ void __launch_bounds__(256) k_fill_i32(int32_t* p, int64_t n, int32_t
     p[i] = v;
 }
 
-// Group ids (stable 64-bit radix sort) and run the batch add. old_out: device int32[n].
+// Group ids (equal ids adjacent, input order inside a group: sort.hip group_keys64) and run the
+// batch add. old_out: device int32[n].
 static int batch_add(Filter* f, const int64_t* ids, const int32_t* counts, int64_t n,
                      int respect_threshold, int32_t* old_out, hipStream_t st) {
-  size_t tmp_bytes = 0;
-  MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, (int64_t*)nullptr, (int64_t*)nullptr,
-                                     (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n, 0, 64, st));
-  tmp_bytes = (tmp_bytes + 255) & ~(size_t)255;
+  const size_t tmp_bytes = (group_keys64_tmp_bytes((size_t)n) + 255) & ~(size_t)255;
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
-  MONO_TRY(f->ws.ensure(n_al * 8 + 2 * n_al * 4 + tmp_bytes));
+  MONO_TRY(f->ws.ensure(n_al * 8 + n_al * 4 + tmp_bytes));
   int64_t* key_out = (int64_t*)f->ws.ptr;
-  uint32_t* idx_in = (uint32_t*)(key_out + n_al);
-  uint32_t* idx_out = idx_in + n_al;
+  uint32_t* idx_out = (uint32_t*)(key_out + n_al);
   void* tmp = idx_out + n_al;
-  hipLaunchKernelGGL(k_iota32, dim3(grid_for(n, 256)), dim3(256), 0, st, idx_in, n);
-  MONO_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, ids, key_out, idx_in, idx_out, (size_t)n, 0,
-                                     64, st));
+  MONO_TRY(group_keys64(ids, nullptr, key_out, idx_out, (size_t)n, tmp, tmp_bytes, st));
   hipLaunchKernelGGL(k_filter_batch_add, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, f->d,
                      key_out, idx_out, n, counts, respect_threshold, old_out);
   MONO_HIP(hipGetLastError());

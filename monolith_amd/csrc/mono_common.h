@@ -90,6 +90,13 @@ size_t sort_pairs_tmp_bytes(size_t n, int end_bit);
 int sort_pairs_u32(const uint32_t* kin, uint32_t* kout, const uint32_t* vin, uint32_t* vout,
                    size_t n, int end_bit, void* tmp, size_t tmp_bytes, hipStream_t st);
 
+// sort.hip: stable GROUPING of 64-bit keys (equal keys adjacent, input order inside a group, groups
+// in no particular order): key_out[j] / val_out[j] = key / value (vin, or the input position when
+// vin == nullptr) of the j-th element of the grouped order. `tmp`: group_keys64_tmp_bytes(n) bytes.
+size_t group_keys64_tmp_bytes(size_t n);
+int group_keys64(const int64_t* keys, const uint32_t* vin, int64_t* key_out, uint32_t* val_out, size_t n,
+                 void* tmp, size_t tmp_bytes, hipStream_t st);
+
 // The fused passes' sticky error word on the current device (never allocates; nullptr only if
 // the device cannot be queried) and the message for a non-zero value read back by the caller.
 uint32_t* sort_error_word();

@@ -77,12 +77,17 @@ __host__ __device__ inline int opt_state_floats(int kind, int dim) {
   return opt_nstate(kind) * dim + opt_nscalar(kind);
 }
 
+constexpr int kLiveStripe0 = 8, kLiveStripes = 64;
+constexpr int kCounterWords = kLiveStripe0 + 8 * kLiveStripes;
 struct TableDev {  // passed to kernels by value
   int64_t* keys;
   uint32_t* ts;
   float* rows;
   uint32_t* special;
-  unsigned long long* counters;  // [0] live rows, [1] tombstones, [2] export cursor
+  unsigned long long* counters;  // [0] live rows (+ the stripes below), [1] tombstones, [2] export
+                                 // cursor; [kLiveStripe0 + 8 k], k < 64: rows inserted since, striped
+                                 // over 64 lines (one word takes ~300 atomics per microsecond: a batch
+                                 // that inserts 17 k rows spent 60 us on it)
   uint64_t cap;
   uint64_t bucket_mask;
   int dim, row_floats, n_seg;
@@ -93,6 +98,16 @@ struct TableDev {  // passed to kernels by value
   const int32_t* slot_expire;  // int32[32768] or nullptr
   SegDev seg[kMaxSeg];
 };
+
+// one row was claimed by this sub-group (`claimed`, wave-divergent): the claims the active lanes
+// of the wave made together go to one stripe with one atomic
+__device__ __forceinline__ void count_claimed(const TableDev& t, bool claimed_sub0) {
+  const unsigned long long cm = __ballot(claimed_sub0);
+  if (cm && (int)(threadIdx.x & 63) == __ffsll((long long)cm) - 1) {
+    const uint32_t stripe = (uint32_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) & (kLiveStripes - 1);
+    atomicAdd(&t.counters[kLiveStripe0 + 8 * stripe], (unsigned long long)__popcll(cm));
+  }
+}
 
 struct Table {
   TableDev d{};
@@ -461,7 +476,7 @@ __global__ void __launch_bounds__(256) k_probe(TableDev t, const int64_t* __rest
 // step; kIlpG rows per lane group in flight.
 template <int LPR, int kIlpG>
 __global__ void __launch_bounds__(256) k_gather_rows4(TableDev t, const uint32_t* __restrict__ slots,
-                                                      int64_t n, float* __restrict__ out) {
+                                                      int64_t n, float* __restrict__ out, int nt) {
   const int l = threadIdx.x % LPR;
   const int64_t ngroups = (int64_t)gridDim.x * (256 / LPR);
   const int D = t.dim, R = t.row_floats;
@@ -478,7 +493,17 @@ __global__ void __launch_bounds__(256) k_gather_rows4(TableDev t, const uint32_t
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int q = 0; q < kIlpG; ++q)
-        if (i0 + q < n) *reinterpret_cast<float4*>(out + (i0 + q) * D + e) = r[q];
+        if (i0 + q < n) {
+          float4* dst = reinterpret_cast<float4*>(out + (i0 + q) * D + e);
+          if (nt) {  // streamed output: not kept in L2 (MONO_GATHER_NT)
+            __builtin_nontemporal_store(r[q].x, &dst->x);
+            __builtin_nontemporal_store(r[q].y, &dst->y);
+            __builtin_nontemporal_store(r[q].z, &dst->z);
+            __builtin_nontemporal_store(r[q].w, &dst->w);
+          } else {
+            *dst = r[q];
+          }
+        }
     }
   }
 }
@@ -629,11 +654,9 @@ __global__ void __launch_bounds__(256) k_find_or_claim(TableDev t, const int64_t
         slot = group_find_or_claim(t, key[q], sub, gshift, &claimed);
         if (claimed) {
           group_init_row(t, key[q], slot, sub);
-          if (sub == 0) {
-            t.ts[slot] = 0;
-            atomicAdd(&t.counters[0], 1ull);
-          }
+          if (sub == 0) t.ts[slot] = 0;
         }
+        count_claimed(t, claimed && sub == 0);
       }
       if (sub == 0) slot_out[i0 + q] = slot;
     }
@@ -682,11 +705,9 @@ __global__ void __launch_bounds__(256) k_claim_pending(TableDev t, const int64_t
         const uint32_t slot = group_find_or_claim(t, key, sub, gshift, &claimed);
         if (claimed) {
           group_init_row(t, key, slot, sub);
-          if (sub == 0) {
-            t.ts[slot] = 0;
-            atomicAdd(&t.counters[0], 1ull);
-          }
+          if (sub == 0) t.ts[slot] = 0;
         }
+        count_claimed(t, claimed && sub == 0);
         if (sub == 0) slot_out[i] = slot;
       }
     }
@@ -818,7 +839,17 @@ struct ApplyArgs {
   uint32_t vl_cap;
   float* packed;
   uint32_t packed_bytes;
+  // apply kernels launched before the host has k_verify's verdict (try_prepared): they do nothing
+  // unless guard[0] == 0 (no id missing), guard[1] == guard_seen (no id changed) and, for a hinted
+  // order, guard[2] == 0 (the lookup brought the hinted ids)
+  const uint32_t* guard;
+  uint32_t guard_seen;
+  int guard_hinted;
 };
+__device__ __forceinline__ bool guard_ok(const ApplyArgs& a) {
+  if (!a.guard) return true;
+  return a.guard[0] == 0u && a.guard[1] == a.guard_seen && (!a.guard_hinted || a.guard[2] == 0u);
+}
 // PTRS: can this instantiation be given per-occurrence source pointers at all? (Only the set-sum
 // mode is; a run-time test in every other kernel's gradient loads cost the headline k_apply a
 // quarter of its speed.)
@@ -1121,6 +1152,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
   const int sub = lane_sub(), gshift = lane_gshift();
   int64_t j = (int64_t)blockIdx.x * (blockDim.x / 8) + threadIdx.x / 8;
   if (j >= a.n) return;
+  if (!guard_ok(a)) return;
   const int D = t.dim, R = t.row_floats;
   uint4 hd = make_uint4(0u, 0u, 0u, 0u);
   if (has_heads) {  // compacted segment heads (k_classify): every sub-group has work
@@ -1195,7 +1227,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       bool claimed;
       slot = group_find_or_claim(t, key, sub, gshift, &claimed);
       fresh = claimed;
-      if (claimed && sub == 0) atomicAdd(&t.counters[0], 1ull);
+      count_claimed(t, claimed && sub == 0);
     }
   }
 
@@ -1539,7 +1571,7 @@ __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a
   const bool vec4 = (D & 3) == 0 && ((a.src_ptrs || a.src_tab) ? a.src_aligned4 != 0
                                                 : (reinterpret_cast<uintptr_t>(a.src) & 15) == 0);
   constexpr bool kSums = MODE == MODE_OPT_DEDUP || MODE == MODE_SET_SUM;
-  const uint32_t nq = *a.qcount;
+  const uint32_t nq = guard_ok(a) ? *a.qcount : 0u;
   // The consumer wave is a lone dependent chain; when this kernel shares CUs with k_apply its
   // issue slots must not be arbitrated away, so it runs at raised wave priority.
   if (!loader) __builtin_amdgcn_s_setprio(3);
@@ -1792,7 +1824,7 @@ __global__ void __launch_bounds__(256, OCC) k_apply_long(TableDev t, ApplyArgs a
 template <int OPTK>
 __global__ void __launch_bounds__(64) k_combine(TableDev t, ApplyArgs a) {
   const int D = t.dim, R = t.row_floats;
-  const uint32_t nc = a.qcount[2];
+  const uint32_t nc = guard_ok(a) ? a.qcount[2] : 0u;
   for (uint32_t ci = blockIdx.x; ci < nc; ci += gridDim.x) {
     const SplitSeg sp = a.cqueue[ci];
     float* row = t.rows + (uint64_t)sp.slot * R;
@@ -2006,7 +2038,7 @@ __global__ void __launch_bounds__(1024) k_long_chain(TableDev t, ApplyArgs a) {
   __shared__ volatile int s_vl_done;
   if (threadIdx.x == 0) atomicAdd(&a.qcount[6], 1u);  // this workgroup has its CU (k_chain_gate)
   const uint32_t nq = a.qcount[0];
-  if (nq == 0) return;
+  if (nq == 0 || !guard_ok(a)) return;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const chain_v4i rs = chain_rsrc(a.packed, a.packed_bytes);
   const uint32_t lds0 = (uint32_t)(uintptr_t)chain_lds;
@@ -2173,7 +2205,7 @@ static int alloc_arrays(TableDev* d, uint64_t cap) {
   MONO_HIP(hipMalloc((void**)&d->ts, (cap + 2) * sizeof(uint32_t)));
   MONO_HIP(hipMalloc((void**)&d->rows, (cap + 2) * (uint64_t)d->row_floats * sizeof(float)));
   MONO_HIP(hipMalloc((void**)&d->special, 2 * sizeof(uint32_t)));
-  MONO_HIP(hipMalloc((void**)&d->counters, 4 * sizeof(unsigned long long)));
+  MONO_HIP(hipMalloc((void**)&d->counters, kCounterWords * sizeof(unsigned long long)));
   return 0;
 }
 
@@ -2189,18 +2221,20 @@ static void free_arrays(TableDev* d) {
 static int reset_arrays(TableDev* d, hipStream_t st) {
   MONO_HIP(hipMemsetAsync(d->keys, 0xFF, d->cap * sizeof(int64_t), st));
   MONO_HIP(hipMemsetAsync(d->special, 0, 2 * sizeof(uint32_t), st));
-  MONO_HIP(hipMemsetAsync(d->counters, 0, 4 * sizeof(unsigned long long), st));
+  MONO_HIP(hipMemsetAsync(d->counters, 0, kCounterWords * sizeof(unsigned long long), st));
   return 0;
 }
 
 static int read_counters(Table* t, hipStream_t st, int64_t* live, int64_t* tombs) {
-  unsigned long long h[2];
+  static thread_local unsigned long long h[kCounterWords];
   uint32_t h_err = 0;
   MONO_HIP(hipMemcpyAsync(h, t->d.counters, sizeof(h), hipMemcpyDeviceToHost, st));
   if (uint32_t* w = sort_error_word())
     MONO_HIP(hipMemcpyAsync(&h_err, w, sizeof(h_err), hipMemcpyDeviceToHost, st));
   MONO_HIP(hipStreamSynchronize(st));
-  *live = (int64_t)h[0];
+  unsigned long long lv = h[0];  // (k_evict subtracts here: the sum is what counts, modulo 2^64)
+  for (int k = 0; k < kLiveStripes; ++k) lv += h[kLiveStripe0 + 8 * k];
+  *live = (int64_t)lv;
   *tombs = (int64_t)h[1];
   return sort_error_report(h_err);  // every host read-back of the write path reports a failed sort
 }
@@ -2235,6 +2269,8 @@ static int rehash(Table* t, uint64_t new_cap, hipStream_t st) {
   MONO_HIP(hipMemcpyAsync(nw.special, t->d.special, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   MONO_HIP(hipMemcpyAsync(nw.counters, t->d.counters, sizeof(unsigned long long),
                           hipMemcpyDeviceToDevice, st));
+  MONO_HIP(hipMemcpyAsync(nw.counters + kLiveStripe0, t->d.counters + kLiveStripe0,
+                          8 * kLiveStripes * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
   MONO_HIP(hipStreamSynchronize(st));
   free_arrays(&t->d);
   t->d = nw;
@@ -2734,9 +2770,13 @@ static void prep_destroy(Table* t) {
 static int launch_gather(Table* t, const uint32_t* slots, int64_t n, float* out, bool aligned,
                          int gather_blocks, int gather_ilp, hipStream_t gs) {
   const int D = t->d.dim;
+  static const int gather_nt = [] {
+    const char* e = getenv("MONO_GATHER_NT");
+    return e ? atoi(e) : 0;
+  }();
 #define MONO_GATHER(LPR, ILP)                                                                       \
   hipLaunchKernelGGL((k_gather_rows4<LPR, ILP>), dim3(grid_for(n, (256 / LPR) * ILP, gather_blocks)), \
-                     dim3(256), 0, gs, t->d, slots, n, out)
+                     dim3(256), 0, gs, t->d, slots, n, out, gather_nt)
 #define MONO_GATHER_L(LPR)                                  \
   do {                                                      \
     if (gather_ilp <= 1) MONO_GATHER(LPR, 1);               \
@@ -2897,10 +2937,37 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
     }
     host_tick("update: pre-pack", &hp);
   }
-  // (tried twice: the apply kernels launched before the host has the verdict, reading the same
-  // flags on the device and doing nothing on "no". Without hints the step is bound by the sort
-  // chain and nothing changes (364 against 355 us); with hints the apply starts 20 us earlier and
-  // runs 50 us longer, beside more of the next chains: 323 against 309 us.)
+  // MONO_SPEC_APPLY=1: the apply kernels are launched before the host has the verdict, reading the
+  // same flags on the device and doing nothing on "no"; the host reads the verdict afterwards.
+  static const bool spec_on = [] {
+    const char* e = getenv("MONO_SPEC_APPLY");
+    return e && atoi(e) != 0;
+  }();
+  bool speculated = false;
+  if (spec_on && !allow_missing && !t->profile && p.mode_class == mode_class(mode)) {
+    ApplyArgs a{};
+    a.skip_slot = kNoSlot;
+    a.n = n;
+    a.src = src;
+    a.mode = mode;
+    a.ts = (uint32_t)req_time;
+    a.global_step = global_step;
+    a.sort_err = sort_error_word();
+    for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
+    a.skeys = p.sslots;
+    a.sidx = p.sidx;
+    a.guard = p.d_flags;
+    a.guard_seen = p.seen_changed;
+    a.guard_hinted = p.hinted ? 1 : 0;
+    uint4* heads = nullptr;
+    MONO_TRY(queue_setup(&a, p.q_base, n, t->d.dim, &heads, st, /*counters_cleared=*/true));
+    const bool rdy = hipEventQuery(p.ev_ready) == hipSuccess;
+    (void)hipGetLastError();
+    MONO_TRY(launch_apply(t, a, heads, a.qcount + 1, st, true, rdy ? nullptr : p.ev_ready, false,
+                          prepacked));
+    speculated = true;
+    host_tick("update: speculative apply launches", &hp);
+  }
   MONO_HIP(hipEventSynchronize(p.ev_verify));
   host_tick("update: sync verify (incl. GPU wait)", &hp);
   const bool changed = p.h_flags[1] != p.seen_changed;
@@ -2917,6 +2984,12 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
     return 0;
   }
   if (n_missing) *n_missing = (int64_t)missed;
+  if (speculated) {  // the kernels are in flight and the verdict says they do the work
+    p.chain_pending = false;
+    MONO_HIP(hipGetLastError());
+    *used = true;
+    return 0;
+  }
   // was the prepared order already complete? (see lookup_prepared: the row gather's throttle)
   bool slack = false;
   {
@@ -2973,10 +3046,7 @@ static int gated_unknown(Table* t, const ApplyArgs& a, const int64_t* ids, int64
                          const int32_t* unknown, const int32_t* pos, int64_t U, hipStream_t st) {
   if (U > 0) {
     const size_t u_al = ((size_t)U + 63) & ~(size_t)63;
-    size_t tmp64 = 0;
-    MONO_HIP(rocprim::radix_sort_pairs(nullptr, tmp64, (int64_t*)nullptr, (int64_t*)nullptr,
-                                       (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)U, 0, 64, st));
-    tmp64 = (tmp64 + 255) & ~(size_t)255;
+    const size_t tmp64 = (group_keys64_tmp_bytes((size_t)U) + 255) & ~(size_t)255;
     const size_t q2 = (queue_bytes(U, t->d.dim) + 255) & ~(size_t)255;
     // a workspace of its own: the first part's arrays are still being read on the device
     MONO_TRY(t->ws_gated.ensure(2 * u_al * sizeof(int64_t) + 2 * u_al * sizeof(uint32_t) + tmp64 + q2));
@@ -2989,8 +3059,9 @@ static int gated_unknown(Table* t, const ApplyArgs& a, const int64_t* ids, int64
     hipLaunchKernelGGL(k_compact_unknown, dim3(grid_for(n, 256)), dim3(256), 0, st, ids, unknown, pos, n,
                        unk_ids, unk_idx);
     MONO_HIP(hipGetLastError());
-    MONO_HIP(rocprim::radix_sort_pairs(tmp2, tmp64, unk_ids, key_out, unk_idx, idx_out2, (size_t)U, 0,
-                                       64, st));
+    // grouped by id (input order inside a group), not sorted: the gated walk only asks where a
+    // group starts and ends
+    MONO_TRY(group_keys64(unk_ids, unk_idx, key_out, idx_out2, (size_t)U, tmp2, tmp64, st));
     ApplyArgs g = a;
     g.n = U;
     g.from_keys = 1;
