@@ -239,6 +239,12 @@ int mono_table_last_phase_ms(void* table, float* h_ms);
  * on the auxiliary stream it is launched on (it runs beside k_apply_long): the figure that is set
  * against rocprofv3's per-kernel average. Profiling must be on. */
 int mono_table_last_apply_kernel_ms(void* table, float* h_ms);
+/* Which path the calls on this table took so far (host counters, no device work; no reference
+ * counterpart: the tests use it to show that a case ran on the path it is meant to cover):
+ * h_counts[4] = {write calls served by the order a lookup prepared, write calls that tried such
+ * an order and fell back to the full path, lookups served by a mono_table_lookup_hint record,
+ * non-empty hint queues dropped}. */
+int mono_table_path_counts(void* table, int64_t* h_counts);
 /* Floats per stored row: dim + optimizer state. */
 int mono_table_row_floats(void* table);
 

@@ -165,8 +165,9 @@ struct Table {
   // times slower than alone, which is why a hint one lookup ahead is not enough: two ahead gives
   // the chain a whole step. The lookup that follows swaps the oldest hint into `prep` (and the
   // hinted slot record into cache_*), checks on the device that its ids are the hinted ones
-  // (k_hint_fix re-probes any that are not and counts them: the order is then not used, and the
-  // queue is dropped) and only gathers the rows. Every call that may change the key set drops the
+  // (k_hint_fix re-probes any that are not and flags it: the order is then not used, and the
+  // queue is dropped; it also re-probes the ids the hint recorded as absent, which a gated update
+  // may have inserted since, without giving up the order) and only gathers the rows. Every call that may change the key set drops the
   // queue.
   static constexpr int kHintDepth = 3;
   struct Hint {
@@ -196,6 +197,10 @@ struct Table {
   int32_t* slot_expire_dev = nullptr;
   Workspace ws;
   Workspace ws_gated;  // the gated remainder of a write call with a hash filter
+  int32_t* h_unk_cnt = nullptr;  // pinned: k_unk_count's per-chunk counts (write_path_gated)
+  // mono_table_path_counts: [0] write calls served by a prepared order, [1] write calls that
+  // tried one and fell back, [2] lookups served by a hint, [3] hint queues dropped non-empty
+  int64_t path_counts[4] = {0, 0, 0, 0};
   // optional per-phase timing of the write path (mono_table_profile)
   bool profile = false;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -554,8 +559,10 @@ __global__ void __launch_bounds__(256) k_hint_fix(TableDev t, const int64_t* __r
     const int64_t i = i0 + lane;
     const bool bad = i < n && ids[i] != rec_ids[i];
     // An id the hinted probe did not find may have been inserted since (a gated update keeps the
-    // queued hints, see write_path): it is probed again, and counted like a wrong hint when it
-    // has appeared — the record is corrected, the hinted order (which skips it) is not used.
+    // queued hints, see write_path): it is probed again and the record corrected, so that the
+    // lookup returns its row. The hinted order stays usable: it carries that position in its
+    // tail of absent ids, which the gated update walks by key and finds in the table
+    // (gated_after_prepared). Only a wrong id makes the order useless.
     const bool again = i < n && !bad && rec_slots[i] == kNoSlot;
     // Both kinds are resolved eight at a time, one position per 8-lane group (a wrong hint makes
     // EVERY position one of them: probed one after the other that cost 0.45 ms per lookup).
@@ -575,15 +582,14 @@ __global__ void __launch_bounds__(256) k_hint_fix(TableDev t, const int64_t* __r
         if (sub == 0) {
           if (was_bad) rec_ids[i0 + l] = key;
           if (was_bad || sl != kNoSlot) rec_slots[i0 + l] = sl;
-          chg = was_bad || sl != kNoSlot;
+          chg = was_bad;
         }
       }
       changed += (uint32_t)__popcll(__ballot(chg));
       for (int q = 0; q < 8 && ma; ++q) ma &= ma - 1;
     }
-    // (a flag, not a count: with a hash filter ~1 % of a batch is inserted per step, and that many
-    // atomics on one word — ~90 retire per microsecond — made this kernel 150 us; the load keeps
-    // the stores to a handful per L2)
+    // (a flag, not a count: single-word atomics retire ~90 per microsecond, and a wholly wrong
+    // hint would issue one per wave; the load keeps the stores to a handful per L2)
     if (lane == 0 && changed && __builtin_nontemporal_load(&flags[2]) == 0u) flags[2] = 1u;
   }
 }
@@ -763,18 +769,86 @@ __global__ void __launch_bounds__(256) k_resolve_known(TableDev t, const int64_t
   }
 }
 
-// ... step 2: the unknown positions, in input order (pos = exclusive scan of `unknown`)
-__global__ void __launch_bounds__(256) k_compact_unknown(const int64_t* __restrict__ ids,
-                                                         const int32_t* __restrict__ unknown,
-                                                         const int32_t* __restrict__ pos, int64_t n,
-                                                         int64_t* __restrict__ unk_ids,
-                                                         uint32_t* __restrict__ unk_idx) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    if (unknown[i]) {
-      unk_ids[pos[i]] = ids[i];
-      unk_idx[pos[i]] = (uint32_t)i;
+// ... step 2: the unknown positions, compacted in input order by two kernels over the same
+// contiguous chunks (one workgroup each): k_unk_count leaves a count per chunk, k_unk_emit sums
+// the counts before its chunk and writes its chunk's unknown positions in order (ballot ranks
+// inside a wave, a four-entry LDS scan across waves). `flag` is k_resolve_known's mark per
+// position.
+constexpr int kUnkMaxChunks = 256;
+struct UnkGeom {
+  int chunks;
+  int64_t chunk;  // positions per chunk, a multiple of 256
+};
+static UnkGeom unk_geom(int64_t n) {
+  UnkGeom g;
+  g.chunks = (int)std::min<int64_t>(kUnkMaxChunks, std::max<int64_t>(1, (n + 1023) / 1024));
+  g.chunk = (((n + g.chunks - 1) / g.chunks) + 255) & ~(int64_t)255;
+  return g;
+}
+__global__ void __launch_bounds__(256) k_unk_count(const uint32_t* __restrict__ flag, int64_t n,
+                                                   int64_t chunk, int32_t* __restrict__ cnt) {
+  __shared__ int s_w[4];
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = std::min<int64_t>(n, lo + chunk);
+  int c = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) c += flag[i] != 0u ? 1 : 0;
+  for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void __launch_bounds__(256) k_unk_emit(const int64_t* __restrict__ ids,
+                                                  const uint32_t* __restrict__ flag, int64_t n,
+                                                  int64_t chunk, const int32_t* __restrict__ cnt,
+                                                  int64_t* __restrict__ unk_ids,
+                                                  uint32_t* __restrict__ unk_idx, int64_t cap) {
+  __shared__ int s_w[4];
+  __shared__ int s_base;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int b = (int)threadIdx.x < (int)blockIdx.x ? cnt[threadIdx.x] : 0;
+  for (int o = 32; o; o >>= 1) b += __shfl_xor(b, o);
+  if (lane == 0) s_w[wave] = b;
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  __syncthreads();
+  int64_t base = s_base;
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = std::min<int64_t>(n, lo + chunk);
+  for (int64_t t0 = lo; t0 < hi; t0 += 256) {
+    const int64_t i = t0 + threadIdx.x;
+    const bool f = i < hi && flag[i] != 0u;
+    const unsigned long long m = __ballot(f);
+    __syncthreads();  // (the previous tile's s_w has been read)
+    if (lane == 0) s_w[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      before += w < wave ? s_w[w] : 0;
+      all += s_w[w];
     }
+    if (f) {
+      const int64_t o = base + before + __popcll(m & ((1ull << lane) - 1ull));
+      if (o < cap) {  // (cap = the count the host sized the arrays for; always holds)
+        unk_ids[o] = ids[i];
+        unk_idx[o] = (uint32_t)i;
+      }
+    }
+    base += all;
+  }
+}
+
+// Behind a prepared order the same list needs no compaction: the order is a stable sort by slot
+// with kNoSlot (all ones in the sorted bits, above every slot) for the ids the lookup did not find,
+// so its last U entries ARE the unknown positions in input order.
+__global__ void __launch_bounds__(256) k_unk_from_order(const int64_t* __restrict__ ids,
+                                                        const uint32_t* __restrict__ order_tail,
+                                                        int64_t U, int64_t n,
+                                                        int64_t* __restrict__ unk_ids,
+                                                        uint32_t* __restrict__ unk_idx) {
+  for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < U;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t i = order_tail[k];
+    unk_idx[k] = i;
+    unk_ids[k] = (int64_t)i < n ? ids[i] : 0;
   }
 }
 
@@ -2684,6 +2758,7 @@ static int bits_for(uint64_t max_value) {
 // Every call that may change the key set (inserts, rehash, evict, clear, import) drops a pending
 // hint and leaves an event behind itself: the next hint's probe waits for it.
 static int hint_drop(Table* t, hipStream_t st) {
+  if (t->hint_count) ++t->path_counts[3];
   // (a hint's probe reads the key array, which a rehash frees: the dropping call waits for it)
   for (int k = 0; k < t->hint_count; ++k) {
     Table::Hint& h = t->hints[(t->hint_head + k) % Table::kHintDepth];
@@ -3039,11 +3114,20 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   return 0;
 }
 
-// The unknown remainder of a gated write call: `unknown[i]` marks the positions whose id the
-// table does not hold, `pos` = its exclusive scan, U = their number. Compacted in input order,
-// grouped by the 64-bit key, walked by the gated head kernel (filter counts, admission, claims).
+// The unknown remainder of a gated write call, U positions in input order: either `flag` marks
+// them (k_resolve_known) and `cnt` = k_unk_count's count per chunk, or `order_tail` lists them
+// (the last U entries of a prepared order). Grouped by the 64-bit key, walked by the gated head
+// kernel (filter counts, admission, claims; an id the table holds after all — inserted since the
+// order was prepared — is found there and updated like any known id, the filter untouched).
+static int unk_count(const uint32_t* flag, int64_t n, int32_t* cnt, hipStream_t st) {
+  const UnkGeom g = unk_geom(n);
+  hipLaunchKernelGGL(k_unk_count, dim3(g.chunks), dim3(256), 0, st, flag, n, g.chunk, cnt);
+  MONO_HIP(hipGetLastError());
+  return 0;
+}
 static int gated_unknown(Table* t, const ApplyArgs& a, const int64_t* ids, int64_t n,
-                         const int32_t* unknown, const int32_t* pos, int64_t U, hipStream_t st) {
+                         const uint32_t* flag, const int32_t* cnt, const uint32_t* order_tail,
+                         int64_t U, hipStream_t st) {
   if (U > 0) {
     const size_t u_al = ((size_t)U + 63) & ~(size_t)63;
     const size_t tmp64 = (group_keys64_tmp_bytes((size_t)U) + 255) & ~(size_t)255;
@@ -3056,8 +3140,14 @@ static int gated_unknown(Table* t, const ApplyArgs& a, const int64_t* ids, int64
     uint32_t* idx_out2 = unk_idx + u_al;
     char* tmp2 = (char*)(idx_out2 + u_al);
     char* q_base2 = tmp2 + tmp64;
-    hipLaunchKernelGGL(k_compact_unknown, dim3(grid_for(n, 256)), dim3(256), 0, st, ids, unknown, pos, n,
-                       unk_ids, unk_idx);
+    if (order_tail) {
+      hipLaunchKernelGGL(k_unk_from_order, dim3(grid_for(U, 256)), dim3(256), 0, st, ids, order_tail, U,
+                         n, unk_ids, unk_idx);
+    } else {
+      const UnkGeom ug = unk_geom(n);
+      hipLaunchKernelGGL(k_unk_emit, dim3(ug.chunks), dim3(256), 0, st, ids, flag, n, ug.chunk, cnt,
+                         unk_ids, unk_idx, U);
+    }
     MONO_HIP(hipGetLastError());
     // grouped by id (input order inside a group), not sorted: the gated walk only asks where a
     // group starts and ends
@@ -3087,30 +3177,27 @@ static int write_path_gated(Table* t, void* filter, ApplyArgs a, const int64_t* 
   const uint32_t skip = (uint32_t)(t->d.cap + 2);
   const int end_bit = bits_for(t->d.cap + 2);
   const size_t tmp32 = (sort_pairs_tmp_bytes((size_t)n, end_bit) + 255) & ~(size_t)255;
-  size_t scan_tmp = 0;
-  MONO_HIP(rocprim::exclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int32_t*)nullptr, 0,
-                                   (size_t)n, rocprim::plus<int32_t>(), st));
-  scan_tmp = (scan_tmp + 255) & ~(size_t)255;
+  const size_t cnt_bytes = kUnkMaxChunks * sizeof(int32_t);
   const size_t q_bytes = (queue_bytes(n, t->d.dim) + 255) & ~(size_t)255;
-  // [slot_in | unknown | pos | slot_out | idx_out | sort scratch | scan scratch | queues]
-  const size_t part1 = 5 * n_al * sizeof(uint32_t) + tmp32 + scan_tmp + q_bytes;
+  // [slot_in | unknown | slot_out | idx_out | sort scratch | chunk counts | queues]
+  const size_t part1 = 4 * n_al * sizeof(uint32_t) + tmp32 + cnt_bytes + q_bytes;
   MONO_TRY(t->ws.ensure(part1));
   uint32_t* slot_in = (uint32_t*)t->ws.ptr;
   int32_t* unknown = (int32_t*)(slot_in + n_al);
-  int32_t* pos = unknown + n_al;
-  uint32_t* slot_out = (uint32_t*)(pos + n_al);
+  uint32_t* slot_out = (uint32_t*)(unknown + n_al);
   uint32_t* idx_out = slot_out + n_al;
   char* tmp = (char*)(idx_out + n_al);
-  char* scan_buf = tmp + tmp32;
-  char* q_base = scan_buf + scan_tmp;
+  int32_t* cnt = (int32_t*)(tmp + tmp32);
+  char* q_base = (char*)cnt + cnt_bytes;
   hipLaunchKernelGGL(k_resolve_known, dim3(grid_for(n, 1024)), dim3(256), 0, st, t->d, ids, n, slot_in,
                      unknown, skip, t->cache_ids, t->cache_slots, t->cache_n);
   MONO_HIP(hipGetLastError());
-  MONO_HIP(rocprim::exclusive_scan(scan_buf, scan_tmp, unknown, pos, 0, (size_t)n,
-                                   rocprim::plus<int32_t>(), st));
-  int32_t h_last[2] = {0, 0};
-  MONO_HIP(hipMemcpyAsync(&h_last[0], pos + (n - 1), 4, hipMemcpyDeviceToHost, st));
-  MONO_HIP(hipMemcpyAsync(&h_last[1], unknown + (n - 1), 4, hipMemcpyDeviceToHost, st));
+  MONO_TRY(unk_count((const uint32_t*)unknown, n, cnt, st));
+  const int n_chunks = unk_geom(n).chunks;
+  if (!t->h_unk_cnt)
+    MONO_HIP(hipHostMalloc((void**)&t->h_unk_cnt, cnt_bytes, hipHostMallocDefault));
+  int32_t* h_cnt = t->h_unk_cnt;
+  MONO_HIP(hipMemcpyAsync(h_cnt, cnt, (size_t)n_chunks * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   MONO_TRY(prep_setup(t, t->prep));  // (its event marks the read-back below)
   MONO_HIP(hipEventRecord(t->prep.ev_verify, st));
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[1], st));
@@ -3131,8 +3218,9 @@ static int write_path_gated(Table* t, void* filter, ApplyArgs a, const int64_t* 
     MONO_HIP(hipGetLastError());
   }
   MONO_HIP(hipEventSynchronize(t->prep.ev_verify));
-  const int64_t U = (int64_t)h_last[0] + h_last[1];
-  MONO_TRY(gated_unknown(t, a, ids, n, unknown, pos, U, st));
+  int64_t U = 0;
+  for (int c = 0; c < n_chunks; ++c) U += h_cnt[c];
+  MONO_TRY(gated_unknown(t, a, ids, n, (const uint32_t*)unknown, cnt, nullptr, U, st));
   if (t->profile) MONO_HIP(hipEventRecord(t->ev[3], st));
   return filter_after_batch(filter, st, U);
 }
@@ -3140,40 +3228,21 @@ static int write_path_gated(Table* t, void* filter, ApplyArgs a, const int64_t* 
 // The gated write path behind a lookup's prepared order (try_prepared with allow_missing): the
 // ids the table holds have just been applied through the prepared order — the positions the
 // lookup did not find carry kNoSlot there and were skipped — and the U unknown ones are exactly
-// those positions: marked from the slot record, compacted in input order, walked by the gated
-// head kernel. No read-back of its own: U is the lookup's miss count k_verify's read-back brought.
-__global__ void __launch_bounds__(256) k_unknown_from_slots(const uint32_t* __restrict__ slots,
-                                                            int64_t n, int32_t* __restrict__ unknown) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x)
-    unknown[i] = slots[i] == kNoSlot ? 1 : 0;
-}
+// those positions: the order's tail (k_unk_from_order), walked by the gated head kernel. No
+// read-back of its own: U is the lookup's miss count k_verify's read-back brought.
 static int gated_after_prepared(Table* t, void* filter, const ApplyArgs& a, const int64_t* ids,
                                 int64_t n, int64_t U, hipStream_t st) {
   if (U > 0) {
     // On the table's own stream, BESIDE the apply kernels of the known ids that try_prepared has
     // just launched on the caller's: a dozen launch-bound kernels over a few per cent of the batch
-    // (scan, compaction, 64-bit sort, gated walk) that touch other rows, other scratch and the
+    // (count, compaction, grouping by id, gated walk) that touch other rows, other scratch and the
     // filter, which the known part never reads. The caller's stream joins before the filter's
     // end-of-batch step.
     Table::Prep& p = t->prep;
     hipStream_t gs = p.stream;
     MONO_HIP(hipStreamWaitEvent(gs, p.ev_verify, 0));  // (the ids are final, the slot record read)
-    const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
-    size_t scan_tmp = 0;
-    MONO_HIP(rocprim::exclusive_scan(nullptr, scan_tmp, (int32_t*)nullptr, (int32_t*)nullptr, 0,
-                                     (size_t)n, rocprim::plus<int32_t>(), gs));
-    scan_tmp = (scan_tmp + 255) & ~(size_t)255;
-    MONO_TRY(t->ws.ensure(2 * n_al * sizeof(int32_t) + scan_tmp));
-    int32_t* unknown = (int32_t*)t->ws.ptr;
-    int32_t* pos = unknown + n_al;
-    char* scan_buf = (char*)(pos + n_al);
-    hipLaunchKernelGGL(k_unknown_from_slots, dim3(grid_for(n, 1024)), dim3(256), 0, gs, t->cache_slots, n,
-                       unknown);
-    MONO_HIP(hipGetLastError());
-    MONO_HIP(rocprim::exclusive_scan(scan_buf, scan_tmp, unknown, pos, 0, (size_t)n,
-                                     rocprim::plus<int32_t>(), gs));
-    MONO_TRY(gated_unknown(t, a, ids, n, unknown, pos, U, gs));
+    MONO_HIP(hipStreamWaitEvent(gs, p.ev_ready, 0));   // (the order is complete)
+    MONO_TRY(gated_unknown(t, a, ids, n, nullptr, nullptr, p.sidx + (n - U), U, gs));
     MONO_HIP(hipEventRecord(p.ev_gated, gs));
     MONO_HIP(hipStreamWaitEvent(st, p.ev_gated, 0));
   }
@@ -3209,6 +3278,8 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
                           &prepared, /*allow_missing=*/from_keys, &missing));
   if (prepared) t->prep_strikes = 0;
   else if (tried) ++t->prep_strikes;
+  if (prepared) ++t->path_counts[0];
+  else if (tried) ++t->path_counts[1];
   if (++t->updates_since_strike >= 64) t->updates_since_strike = t->prep_strikes = 0;
   t->expect_update = pattern && t->prep_strikes < 2;
   if (prepared && !from_keys) return 0;
@@ -3557,6 +3628,7 @@ static int lookup_impl(Table* t, const int64_t* ids, int64_t n, float* out, hipS
     oldest->p.n = 0;
     t->hint_head = (t->hint_head + 1) % Table::kHintDepth;
     --t->hint_count;
+    ++t->path_counts[2];
     Table::Prep& p = t->prep;
     // (the whole chain, not just the probe: k_hint_fix may rewrite slots the sort is reading. In
     // steady state the chain finished long ago, beside the update before this lookup.)
@@ -3776,6 +3848,7 @@ int mono_table_destroy(void* table) {
   t->ws.release();
   t->ws_gated.release();
   t->ws_pack.release();
+  if (t->h_unk_cnt) (void)hipHostFree(t->h_unk_cnt);
   for (int i = 0; i < 4; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);
   for (int i = 0; i < 2; ++i)
@@ -3817,6 +3890,13 @@ int mono_table_last_apply_kernel_ms(void* table, float* h_ms) {
                "write call since it was switched on forked k_apply: 96 ids or fewer, a filter)");
   MONO_HIP(hipEventSynchronize(t->ev_k[1]));
   MONO_HIP(hipEventElapsedTime(h_ms, t->ev_k[0], t->ev_k[1]));
+  return 0;
+}
+
+int mono_table_path_counts(void* table, int64_t* h_counts) {
+  MONO_REQUIRE(table && h_counts, "mono_table_path_counts: null argument");
+  Table* t = (Table*)table;
+  for (int k = 0; k < 4; ++k) h_counts[k] = t->path_counts[k];
   return 0;
 }
 

@@ -12,3 +12,5 @@ t0 = rows[i0][1]
 for r in rows[i0:i1]:
   print("%-84s %8.1f %8.1f  s%s" % (r[0][:84], (r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[3]))
 print("step span us: %.1f" % ((rows[i1][1] - t0) / 1e3))
+per = [(rows[b][1] - rows[a][1]) / 1e3 for a, b in zip(idx[:-1], idx[1:])]
+print("marker periods us:", " ".join("%.0f" % p for p in per))
