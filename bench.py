@@ -571,10 +571,14 @@ def main_config5(args, device):
     made[j] = make_ids(j)
   torch.cuda.synchronize()
 
+  marks = {}  # an event at the start of every step: the period of a step that does not evict
+
   def step(i):
     ids = made.pop(i)
     now = now0 + 3600 * (i + 1)
     t = state["t"]
+    marks[i] = torch.cuda.Event(enable_timing=True)
+    marks[i].record()
     t.lookup(ids)
     for a in range(1, ahead + 1):
       t.lookup_hint(made[i + a], a)
@@ -592,6 +596,8 @@ def main_config5(args, device):
   dt = _timed_steps(step, args, torch.cuda.synchronize)
   rows1 = state["t"].size()
   inserted = rows1 - rows0 + state["evicted_rows"]
+  periods = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.warmup, args.warmup + args.steps - 1)
+             if i + 1 in marks]
   uniq = float(np.mean([torch.unique(b).numel() / n for b in pool]))
   # phases of the steps that follow, each on its own ids (lookup announced as in the timed loop)
   i0 = args.warmup + args.steps
@@ -641,6 +647,10 @@ def main_config5(args, device):
                    "achieved": step_bytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                    "frac": step_bytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
                    "algorithmic_bytes": step_bytes, "phase_ms": ph,
+                   # (HIP events at the start of every timed step: the median is a step that does
+                   # not evict; ms_per_step above averages the two evictions and what follows in)
+                   "step_period_ms_median": float(np.median(periods)) if periods else None,
+                   "step_period_ms_max": float(np.max(periods)) if periods else None,
                    "k_evict_ms": evict_ms, "k_evict_slots": cap_slots,
                    "k_evict_GBps": cap_slots * 12 / (evict_ms * 1e-3) / 1e9 if evict_ms == evict_ms else None,
                    "k_evict_frac": (cap_slots * 12 / (evict_ms * 1e-3) / 1e9 / HBM_PEAK_GBS

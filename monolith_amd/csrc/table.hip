@@ -1160,9 +1160,14 @@ __device__ __forceinline__ uint32_t long_blocks(const ApplyArgs& a, int64_t len)
 }
 // queue entries q .. q + nparts; a split key also takes partial rows pbase .. + nparts and the
 // split-key entry c; packed blocks blk .. + long_blocks (all four reserved by the caller)
+// `wg_list` (LDS, kClsBlkList entries, `wg_n` its counter): the caller's workgroup writes the
+// block descriptors of the listed parts together afterwards (write_block_list) — one lane doing
+// it for a 30 000-row segment is a 470-iteration loop that the whole workgroup waits for.
+constexpr int kClsBlkList = 64;
 __device__ inline void enqueue_long_at(const ApplyArgs& a, int64_t first, int64_t end, int64_t key,
                                        uint32_t slot, uint32_t fresh, uint32_t q, uint32_t pbase,
-                                       uint32_t c, uint32_t blk) {
+                                       uint32_t c, uint32_t blk, uint4* wg_list = nullptr,
+                                       uint32_t* wg_n = nullptr) {
   const int64_t len = end - first;
   const bool split = long_split(a, len);
   const uint32_t nparts = long_parts(a, len);
@@ -1182,15 +1187,32 @@ __device__ inline void enqueue_long_at(const ApplyArgs& a, int64_t first, int64_
     a.queue[q + p] = ls;
     const int64_t plen = ls.end - ls.first;
     if (a.blk_src) {
-      for (int64_t r = 0; r < plen; r += kPackRows, ++blk)
-        if (blk < a.blk_cap)  // (always: the host sizes blk_src for the worst case)
-          a.blk_src[blk] = make_uint2((uint32_t)(ls.first + r), (uint32_t)min((int64_t)kPackRows, plen - r));
+      const uint32_t li = wg_list && plen > 4 * kPackRows ? atomicAdd(wg_n, 1u) : (uint32_t)kClsBlkList;
+      if (li < (uint32_t)kClsBlkList) {
+        wg_list[li] = make_uint4((uint32_t)ls.first, (uint32_t)plen, blk, 0u);
+        blk += (uint32_t)((plen + kPackRows - 1) / kPackRows);
+      } else {
+        for (int64_t r = 0; r < plen; r += kPackRows, ++blk)
+          if (blk < a.blk_cap)  // (always: the host sizes blk_src for the worst case)
+            a.blk_src[blk] = make_uint2((uint32_t)(ls.first + r), (uint32_t)min((int64_t)kPackRows, plen - r));
+      }
       if (plen > kVeryLong) {  // (rare: a direct global atomic per entry)
         const int cl = vl_class(plen);
         const uint32_t i = atomicAdd(&a.qcount[8 + cl], 1u);
         if (i < a.vl_cap) a.vlq[(uint32_t)cl * a.vl_cap + i] = q + p;
       }
     }
+  }
+}
+// (all threads of the workgroup, after a barrier behind the enqueue_long_at calls)
+__device__ inline void write_block_list(const ApplyArgs& a, const uint4* wg_list, uint32_t n_list) {
+  n_list = min(n_list, (uint32_t)kClsBlkList);
+  for (uint32_t e = 0; e < n_list; ++e) {
+    const uint4 d = wg_list[e];  // (first sorted position, rows, first block)
+    const uint32_t nb = (d.y + kPackRows - 1) / kPackRows;
+    for (uint32_t r = threadIdx.x; r < nb; r += blockDim.x)
+      if (d.z + r < a.blk_cap)
+        a.blk_src[d.z + r] = make_uint2(d.x + r * kPackRows, min((uint32_t)kPackRows, d.y - r * kPackRows));
   }
 }
 __device__ inline void enqueue_long(const ApplyArgs& a, int64_t first, int64_t end, int64_t key,
@@ -1531,14 +1553,15 @@ constexpr int kClsThreads = 1024;
 constexpr int kClsItems = 4;
 __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow_long,
                                                           uint4* __restrict__ heads) {
-  __shared__ uint32_t s_cnt, s_base, s_lq, s_lp, s_lc, s_lb, s_lqb, s_lpb, s_lcb, s_lbb;
+  __shared__ uint32_t s_cnt, s_base, s_lq, s_lp, s_lc, s_lb, s_lqb, s_lpb, s_lcb, s_lbb, s_nl;
+  __shared__ uint4 s_ll[kClsBlkList];
   const uint32_t* __restrict__ sk = static_cast<const uint32_t*>(a.skeys);
   const int64_t n = a.n;
   const int tid = threadIdx.x, lane = tid & 63;
   // a sort that failed (look-back time-out) leaves stale ping-pong data behind: emit no heads and
   // no long segments, so that nothing is applied; the host reports the word at its next read-back
   if (a.sort_err && *a.sort_err != 0u) return;
-  if (tid == 0) s_cnt = s_lq = s_lp = s_lc = s_lb = 0;
+  if (tid == 0) s_cnt = s_lq = s_lp = s_lc = s_lb = s_nl = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * (kClsThreads * kClsItems);
   uint32_t loc[kClsItems], len[kClsItems], slotv[kClsItems], idxv[kClsItems];
@@ -1602,7 +1625,11 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
     if (sh[k]) heads[gb + loc[k]] = make_uint4((uint32_t)j, len[k], slotv[k], idxv[k]);
     if (lq[k] != kNoPart)
       enqueue_long_at(a, j, j + len[k], 0, slotv[k], 0u, s_lqb + lq[k], s_lpb + lp[k], s_lcb + lc[k],
-                      s_lbb + lb[k]);
+                      s_lbb + lb[k], s_ll, &s_nl);
+  }
+  if (a.blk_src) {
+    __syncthreads();
+    write_block_list(a, s_ll, s_nl);
   }
 }
 
