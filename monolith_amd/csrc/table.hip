@@ -2490,7 +2490,15 @@ static unsigned chain_wgs(const Table* t) {
     const char* e = getenv("MONO_CHAIN_WGS");
     return e ? std::max(1, std::min(atoi(e), 256)) : 24;
   }();
-  return t->d.keys ? (unsigned)v : 256u;
+  // The stateless sums (layout gradient, exchange gradient) have no table traffic to protect, but
+  // their short runs are summed by k_apply on the CUs the chains leave free: 64 chain CUs beside
+  // 192 for k_apply (config 3's layout gradient: 0.92 ms with 256, 0.85 with 128, 0.79 with 64,
+  // 0.85 with 40). MONO_CHAIN_WGS_CTX overrides.
+  static const int c = [] {
+    const char* e = getenv("MONO_CHAIN_WGS_CTX");
+    return e ? std::max(1, std::min(atoi(e), 256)) : 64;
+  }();
+  return t->d.keys ? (unsigned)v : (unsigned)c;
 }
 template <int OPTK, int MODE>
 static int launch_chain_om(const Table* t, const ApplyArgs& a, hipStream_t st) {
@@ -2706,8 +2714,7 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
   MONO_HIP(hipStreamWaitEvent(t->aux, gated ? t->ev_pack : t->ev_fork, 0));
   if (ready && !gated) MONO_HIP(hipStreamWaitEvent(t->aux, ready, 0));
   host_tick(a.mode == MODE_SET_SUM ? "gradsum: aux waits" : "apply: aux waits", &hp);
-  // (the stateless sums launch one chain workgroup per CU: nothing to keep the sub-group kernel from)
-  if (gated && t->d.keys)
+  if (gated && chain_wgs(t) < 256u)
     hipLaunchKernelGGL(k_chain_gate, dim3(1), dim3(64), 0, t->aux, a.qcount + 6, chain_wgs(t), 40u);
   if (t->profile) MONO_HIP(hipEventRecord(t->ev_k[0], t->aux));
   launch_short(t, a, t->aux);
