@@ -2732,7 +2732,7 @@ static int launch_apply(Table* t, ApplyArgs& a, uint4* heads, uint32_t* nheads, 
 
 // Scratch behind the apply kernels: counters, long-segment queue, split-key queue, chunk sums,
 // compacted heads.
-// MONO_EXACT_ORDER=1 (read once per process): no key is ever split, every sum runs strictly in
+// Default: no key is ever split, every sum runs strictly in
 // input order at any length — the reference's own order bit for bit, at the price of one
 // dependent chain per hot key (deviation 1).
 static int chunk_size() {  // MONO_CHUNK=<rows>: sum hot keys in chunks, clamped to [256, 1 << 20]
