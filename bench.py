@@ -130,7 +130,16 @@ def main_sharded(args, rank, world, device):
         cfgs, lambda slot, c: hash_table_ops.hash_table_from_config(
             c, name_suffix="bench_%s_%d" % (slot, idx)))
 
-  table = distributed_ps_sync.DistributedMultiTypeHashTableMpi(world, factory)
+  # the first half of the next lookup (reorder, size + FID exchange, the owner's slot resolution)
+  # beside the update: the reference's enable_pipelined_fwda2a, without its stale rows
+  # (N > 1 only: at N = 1 there is no exchange to move and the step is bound by launch work, where
+  # the extra launches cost more than they save — 0.92 against 0.81 ms; MONO_BENCH_PIPELINED
+  # overrides either way, = 2 adds the owner-side lookup hint)
+  pl = os.environ.get("MONO_BENCH_PIPELINED", "1" if world > 1 else "0")
+  pipelined = not args.no_prefetch and pl != "0"
+  qc = {"enable_pipelined_fwda2a": 1, "announce_owner_lookup": 1 if pl == "2" else 0}
+  table = distributed_ps_sync.DistributedMultiTypeHashTableMpi(
+      world, factory, queue_configs=qc if pipelined else None)
   local = table._table._hash_tables["criteo"]
   # populate this rank's shard: fid = slot << 48 | r with floormod(fid, N) == rank
   chunk = 1 << 22
@@ -184,6 +193,8 @@ def main_sharded(args, rank, world, device):
     state["t"] = state["t"].apply_gradients({"criteo": (ids["criteo"], grad)}, bundle,
                                             global_step=i, req_time=10 + i,
                                             next_slot_to_id=nxt if where == "grad" else None)
+    if pipelined and where != "grad":  # the reorder began behind the lookup; its sequel here
+      state["pack"] = state["t"].prefetch_forward(nxt, state.pop("pack", None))
     return emb
 
   def barrier():
@@ -227,6 +238,9 @@ def main_sharded(args, rank, world, device):
                  "fids_per_step_per_gpu": n, "unique_ratio_per_rank": uniq, "skew": args.skew,
                  "parallelism": "table sharded over %d GPUs, all-to-all exchange" % world,
                  "reorder": "one batch ahead on a side stream" if side else "in line",
+                 "pipelined_forward": ("size + FID exchange of the next batch beside the update"
+                                       + (" + owner lookup announced" if pl == "2" else ""))
+                                      if pipelined else "off",
                  "populate_s": t_pop, "table_rows": total_rows},
       "roofline": {"bound": "hbm", "kernel": "whole step (per GPU)", "achieved": step_gbs,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,

@@ -255,6 +255,13 @@ int mono_tables_fused_lookup(void* const* tables, int K, const int64_t* ids,
                              const int32_t* h_fused_slot_size, int N, float* out_emb,
                              int32_t* h_emb_splits, int32_t* h_id_offsets, int32_t* h_emb_offsets,
                              int32_t* h_emb_sizes, void* stream);
+/* The lookup hint (mono_table_lookup_hint) for the fused lookup that is `ahead` calls away: same
+ * ids / h_fused_slot_size / N as mono_tables_fused_lookup will be given. No counterpart in the
+ * reference (its prefetch queues, distributed_ps_sync.py:218-224, run the whole lookup ahead and
+ * accept stale rows; this resolves slots ahead and gathers rows in line, so nothing is stale).
+ * Takes effect for K == 1; a no-op otherwise. The ids must stay valid until that lookup is issued. */
+int mono_tables_fused_lookup_hint(void* const* tables, int K, const int64_t* ids,
+                                  const int32_t* h_fused_slot_size, int N, int ahead, void* stream);
 /* ops/hash_table_update_op.cc:174-262 (MonolithHashTableFusedOptimize). */
 int mono_tables_fused_apply_gradient(void* const* tables, void* const* filters, int K,
                                      const int64_t* ids, const int32_t* h_fused_slot_size,

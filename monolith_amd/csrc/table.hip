@@ -153,6 +153,11 @@ struct Table {
     uint32_t* d_blk_miss = nullptr;  // [kProbeMaxBlocks]
     int probe_blocks = 0;
     uint32_t* h_flags = nullptr;  // pinned host copy
+    // recorded on the caller's stream behind the update that used this order: a hint that
+    // recycles the slot (its arrays, the slot record swapped out with it) may come from another
+    // stream than the table's lookups and updates, and waits for it
+    hipEvent_t ev_consumed = nullptr;
+    bool consumed_set = false;
     uint32_t seen_changed = 0;    // d_flags[1] as of the last read-back (it only grows)
     bool chain_pending = false;   // a sort + classify chain was launched and the caller's stream
                                   // has not waited for it since
@@ -2833,6 +2838,7 @@ static int prep_setup(Table* t, Table::Prep& p) {
   MONO_HIP(hipEventCreateWithFlags(&p.ev_ready, hipEventDisableTiming));
   MONO_HIP(hipEventCreateWithFlags(&p.ev_verify, hipEventDisableTiming));
   MONO_HIP(hipEventCreateWithFlags(&p.ev_gated, hipEventDisableTiming));
+  MONO_HIP(hipEventCreateWithFlags(&p.ev_consumed, hipEventDisableTiming));
   MONO_HIP(hipMalloc((void**)&p.d_flags, 256));
   MONO_HIP(hipMemset(p.d_flags, 0, 256));
   MONO_HIP(hipMalloc((void**)&p.d_blk_miss, kProbeMaxBlocks * sizeof(uint32_t)));
@@ -2847,6 +2853,7 @@ static void prep_destroy_one(Table::Prep& p) {
   if (p.ev_ready) (void)hipEventDestroy(p.ev_ready);
   if (p.ev_verify) (void)hipEventDestroy(p.ev_verify);
   if (p.ev_gated) (void)hipEventDestroy(p.ev_gated);
+  if (p.ev_consumed) (void)hipEventDestroy(p.ev_consumed);
   if (p.d_flags) (void)hipFree(p.d_flags);
   if (p.d_blk_miss) (void)hipFree(p.d_blk_miss);
   if (p.h_flags) (void)hipHostFree(p.h_flags);
@@ -3316,7 +3323,11 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   else if (tried) ++t->path_counts[1];
   if (++t->updates_since_strike >= 64) t->updates_since_strike = t->prep_strikes = 0;
   t->expect_update = pattern && t->prep_strikes < 2;
-  if (prepared && !from_keys) return 0;
+  if (prepared && !from_keys) {
+    MONO_HIP(hipEventRecord(t->prep.ev_consumed, st));
+    t->prep.consumed_set = true;
+    return 0;
+  }
   // Everything below may insert keys (and move them: rehash): a pending hint is stale, and the
   // next one waits for what this call enqueues. The exception is the gated remainder behind a
   // prepared order: the table has room (no rehash, checked above), an insertion moves no row, and
@@ -3349,7 +3360,10 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
     // and the unknown ids are being inserted now)
     t->prep.n = 0;
     t->used_upper += missing;
-    return gated_after_prepared(t, filter, a, ids, n, missing, st);
+    MONO_TRY(gated_after_prepared(t, filter, a, ids, n, missing, st));
+    MONO_HIP(hipEventRecord(t->prep.ev_consumed, st));
+    t->prep.consumed_set = true;
+    return 0;
   }
 
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
@@ -3725,6 +3739,7 @@ static int lookup_hint(Table* t, const int64_t* ids, int64_t n, int ahead, hipSt
   // NOT for updates through the prepared order, which never do.
   MONO_HIP(hipEventRecord(t->ev_hint_src, hs));
   MONO_HIP(hipStreamWaitEvent(p.stream, t->ev_hint_src, 0));
+  if (p.consumed_set) MONO_HIP(hipStreamWaitEvent(p.stream, p.ev_consumed, 0));
   if (t->ev_keys_set) MONO_HIP(hipStreamWaitEvent(p.stream, t->ev_keys, 0));
   MONO_TRY(lookup_prepared(t, p, ids, n, nullptr, false, hs, /*hint=*/true, h.ids, h.slots));
   ++t->hint_count;
@@ -4158,6 +4173,23 @@ int mono_tables_fused_lookup(void* const* tables, int K, const int64_t* ids,
                                out_emb + h_emb_offsets[idx], stream));
   }
   return 0;
+}
+
+int mono_tables_fused_lookup_hint(void* const* tables, int K, const int64_t* ids,
+                                  const int32_t* h_fused_slot_size, int N, int ahead, void* stream) {
+  MONO_REQUIRE(tables && K > 0 && N > 0 && h_fused_slot_size,
+               "mono_tables_fused_lookup_hint: bad argument");
+  // One table: the fused lookup is ONE mono_table_lookup over the shard-major id list, and that
+  // is what is announced. K > 1 runs one lookup per (shard, table) cell — up to N per table and
+  // step, more than a hint queue holds: not announced (the lookups resolve their ids themselves).
+  if (K != 1) return 0;
+  int64_t total = 0;
+  for (int idx = 0; idx < N; ++idx) {
+    MONO_REQUIRE(h_fused_slot_size[idx] >= 0, "mono_tables_fused_lookup_hint: negative slot size");
+    total += h_fused_slot_size[idx];
+  }
+  if (total == 0) return 0;
+  return mono_table_lookup_hint(tables[0], ids, total, ahead, stream);
 }
 
 int mono_tables_fused_apply_gradient(void* const* tables, void* const* filters, int K,

@@ -10,6 +10,14 @@ step is
   apply_gradients:  F2 gradient (in-order scatter-add) -> a2a-v(grads fp32, splits swapped)
                     -> fused multi-table optimize on the owner
 
+Pipelining (queue_configs["enable_pipelined_fwda2a"] > 0, the reference's switch,
+distributed_ps_sync.py:218-224): apply_gradients(next_slot_to_id=...) runs the FIRST HALF of the
+next batch's lookup — reorder, size exchange with its host read-back, FID exchange, and the
+owner's slot resolution + update order (fused_lookup_hint) — on a side stream beside this batch's
+update; the lookup that follows only gathers rows, exchanges them and runs F2. The reference's
+queues run the whole lookup ahead and train on stale rows; here the rows are read after the
+update has landed, so the result is the serial one bit for bit (the tests compare them).
+
 The reference's Horovod / BytePS alltoall (distributed_ps_sync.py:170-193,230-283,369-496) is
 `torch.distributed.all_to_all_single` here: RCCL over xGMI on the GPUs (backend "nccl"), gloo in
 the CPU tests. Message sizes are exchanged explicitly (hvd.alltoall(shard_sizes)); the rows /
@@ -71,6 +79,22 @@ def alltoall(tensor: torch.Tensor, splits, recv_splits=None, group=None):
   return out, recv_splits
 
 
+class ForwardPrefetch:
+  """The first half of a lookup, done ahead (see the module docstring): what lookup() needs to go
+  on from the owner's fused lookup. `event` marks its end on the stream it ran on."""
+
+  def __init__(self, sorted_slot_keys, pack, id_flat_t, id_size_np, sss_np, event):
+    self.sorted_slot_keys = sorted_slot_keys
+    self.pack = pack
+    self.id_flat_t = id_flat_t
+    self.id_size_np = id_size_np
+    self.sss_np = sss_np
+    self.event = event
+
+  def result(self):  # (a caller that only wants the reorder, as from a ReorderHandle)
+    return self.pack
+
+
 class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTable):
   """distributed_ps_sync.py:110-545. table_factory(rank) builds this rank's local
   (Merged)MultiTypeHashTable; it must offer fused_lookup / fused_apply_gradient /
@@ -101,31 +125,22 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
     self._world_size = world
     self._side_stream = None
     self._prefetched = None
-    self._queue_configs = queue_configs or {}  # pipelining queues of the reference: not needed,
-    # the exchange is stream-ordered
+    # The reference's pipelining queues. enable_pipelined_fwda2a > 0: the first half of the next
+    # lookup runs beside the update (module docstring). The others (embedding_prefetch_capacity,
+    # enable_async_optimize, enable_pipelined_bwda2a) trade staleness for overlap in the reference;
+    # they are accepted and have no effect: every exchange here is stream-ordered.
+    # "announce_owner_lookup" (no reference counterpart) adds the owner's fused_lookup_hint to the
+    # first half: fewer kernels in line, more launches — pays when the step is not host-bound.
+    self._queue_configs = queue_configs or {}
+    self._pipelined_fwd = int(self._queue_configs.get("enable_pipelined_fwda2a", 0)) > 0
+    self._announce = int(self._queue_configs.get("announce_owner_lookup", 0)) > 0
     if ops is None:
       from monolith_amd import distribution_ops as ops  # HIP ops; raises without the library
     self._ops = ops
 
-  def lookup(self, slot_to_id: Dict[str, torch.Tensor], auxiliary_bundle: Dict,
-             early_reorder_indicies_res_pack=None):
-    sorted_slot_keys = sorted(slot_to_id.keys())
-    slot_num = len(slot_to_id)
-    sorted_input = [slot_to_id[k] for k in sorted_slot_keys]
-    if early_reorder_indicies_res_pack:
-      if hasattr(early_reorder_indicies_res_pack, "result"):  # a reorder still in flight
-        early_reorder_indicies_res_pack = early_reorder_indicies_res_pack.result()
-      all_fids, shard_sizes, sharded_slot_sizes, fused_embedding_offsets = \
-          early_reorder_indicies_res_pack
-    else:
-      # (a reorder started ahead and never asked for would leave the library waiting for its
-      # finish: retire it before this batch's own)
-      stale, self._prefetched = self._prefetched, None
-      if stale is not None and hasattr(stale, "result"):
-        stale.result()
-      all_fids, shard_sizes, sharded_slot_sizes, fused_embedding_offsets = \
-          self._ops.fused_reorder_by_indices(sorted_input, self._shard_num, self._output_dims)
-
+  def _exchange_ids(self, slot_num, pack):
+    """Size exchange + FID exchange of a reordered batch: (id_flat_t, id_size_np [N, K], sss_np)."""
+    all_fids, shard_sizes, sharded_slot_sizes, _ = pack
     # M: num_of_ids, N: num_of_shards, K: num_of_merged_tables, E: total embedding floats.
     # id_flat_t: [M'], id_size_flat_t: [K*N] (source-shard major)
     # The per-(shard, slot) counts travel first (fixed size, K per peer): their row sums are the
@@ -147,6 +162,39 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
     recv_fid_splits = id_size_np.sum(1).tolist()
     id_flat_t, _ = alltoall(all_fids, shard_sizes_h, recv_splits=recv_fid_splits,
                             group=self._group)
+    return id_flat_t, id_size_np, sss_np
+
+  def lookup(self, slot_to_id: Dict[str, torch.Tensor], auxiliary_bundle: Dict,
+             early_reorder_indicies_res_pack=None):
+    sorted_slot_keys = sorted(slot_to_id.keys())
+    slot_num = len(slot_to_id)
+    sorted_input = [slot_to_id[k] for k in sorted_slot_keys]
+    ahead = None
+    if isinstance(early_reorder_indicies_res_pack, ForwardPrefetch):
+      ahead = early_reorder_indicies_res_pack
+      assert ahead.sorted_slot_keys == sorted_slot_keys, "prefetched lookup of other slots"
+      early_reorder_indicies_res_pack = ahead.pack
+      if ahead.event is not None:  # (its kernels and collectives ran on the side stream)
+        cur = torch.cuda.current_stream(ahead.id_flat_t.device)
+        cur.wait_event(ahead.event)
+        ahead.id_flat_t.record_stream(cur)  # (allocated under the side stream, read here)
+    if early_reorder_indicies_res_pack:
+      if hasattr(early_reorder_indicies_res_pack, "result"):  # a reorder still in flight
+        early_reorder_indicies_res_pack = early_reorder_indicies_res_pack.result()
+      pack = early_reorder_indicies_res_pack
+    else:
+      # (a reorder started ahead and never asked for would leave the library waiting for its
+      # finish: retire it before this batch's own)
+      stale, self._prefetched = self._prefetched, None
+      if stale is not None and hasattr(stale, "result"):
+        stale.result()
+      pack = self._ops.fused_reorder_by_indices(sorted_input, self._shard_num, self._output_dims)
+    all_fids, shard_sizes, sharded_slot_sizes, fused_embedding_offsets = pack
+
+    if ahead is not None:
+      id_flat_t, id_size_np, sss_np = ahead.id_flat_t, ahead.id_size_np, ahead.sss_np
+    else:
+      id_flat_t, id_size_np, sss_np = self._exchange_ids(slot_num, pack)
     id_size_flat_h = torch.from_numpy(id_size_np.reshape(-1))
     auxiliary_bundle["shard_sizes"] = shard_sizes
     auxiliary_bundle["fused_embedding_offsets"] = fused_embedding_offsets
@@ -172,6 +220,44 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
                                                          self._output_dims)
     slot_to_embedding = {k: outputs[i] for i, k in enumerate(sorted_slot_keys)}
     return slot_to_embedding, auxiliary_bundle
+
+  def prefetch_forward(self, next_slot_to_id: Dict[str, torch.Tensor], handle=None):
+    """The first half of the NEXT lookup, now: finish (or run) its reorder, exchange its sizes
+    and FIDs, optionally announce the owner's lookup. Call it right after apply_gradients() has
+    launched the update — the host waits in here for the reorder's sizes and the size exchange,
+    beside that update instead of in the step — and pass the result to lookup(...,
+    early_reorder_indicies_res_pack=...). `handle`: a reorder_begin() of the same ids started
+    earlier (the earlier the better: it then has the whole backward pass to finish)."""
+    keys = sorted(next_slot_to_id.keys())
+    first = next_slot_to_id[keys[0]]
+    on_gpu = isinstance(first, torch.Tensor) and first.is_cuda
+    if on_gpu:
+      if self._side_stream is None:
+        self._side_stream = torch.cuda.Stream(first.device)
+      side = self._side_stream
+      if handle is None:
+        # the reorder runs here: behind whatever produced the ids on the current stream. (With a
+        # handle the side stream must NOT wait for the current one — that is the update just
+        # launched; result() orders it behind the reorder's own stream.)
+        side.wait_stream(torch.cuda.current_stream(first.device))
+        for v in next_slot_to_id.values():
+          if isinstance(v, torch.Tensor) and v.is_cuda:
+            v.record_stream(side)
+      ctx = torch.cuda.stream(side)
+    else:  # (host tensors: the CPU tests' oracle ops, no streams)
+      import contextlib
+      side, ctx = None, contextlib.nullcontext()
+    with ctx:
+      if handle is None:
+        handle = self._ops.fused_reorder_by_indices([next_slot_to_id[k] for k in keys],
+                                                    self._shard_num, self._output_dims)
+      pack = handle.result() if hasattr(handle, "result") else handle
+      id_flat_t, id_size_np, sss_np = self._exchange_ids(len(keys), pack)
+      hint = getattr(self._table, "fused_lookup_hint", None) if self._announce else None
+      if hint is not None and id_flat_t.is_cuda and id_flat_t.numel():
+        hint(id_flat_t, id_size_np.reshape(-1), self._shard_num, 1)
+      event = side.record_event() if side is not None else None
+    return ForwardPrefetch(keys, pack, id_flat_t, id_size_np, sss_np, event)
 
   def reorder_begin(self, slot_to_id: Dict[str, torch.Tensor]):
     """Start the reorder of a coming batch (on the current stream, without waiting for it) and
@@ -219,7 +305,7 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
       grad_flat_t = grad_flat_t.to(torch.float32)
     auxiliary_bundle.pop("shard_sizes")
     prefetched = None
-    if next_slot_to_id is not None:
+    if next_slot_to_id is not None and grad_flat.is_cuda:
       if self._side_stream is None:
         self._side_stream = torch.cuda.Stream(grad_flat.device)
       # the next batch's ids may come out of work on the current stream (an H2D copy, id
@@ -236,6 +322,9 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
         auxiliary_bundle.pop("id_offsets"), auxiliary_bundle.pop("emb_offsets"), global_step,
         req_time, self._shard_num)
     updated = self._copy_with_new_table(updated_table)
+    if next_slot_to_id is not None and self._pipelined_fwd:
+      # behind the update's launches: the host wait inside costs the step nothing
+      prefetched = updated.prefetch_forward(next_slot_to_id, prefetched)
     updated._prefetched = prefetched
     return updated
 

@@ -511,6 +511,29 @@ def fused_lookup(tables: List, ids, fused_slot_size, num_of_shards: int):
           torch.from_numpy(emb_sizes))
 
 
+_fused_hint_keep: List = []
+
+
+def fused_lookup_hint(tables: List, ids, fused_slot_size, num_of_shards: int, ahead: int = 1) -> None:
+  """mono_tables_fused_lookup_hint (no counterpart in the reference's op set): announces the
+  fused_lookup(tables, ids, fused_slot_size, num_of_shards) that is `ahead` calls away, so that it
+  only has to gather rows. Never changes a result; takes effect for one table."""
+  res, hs = _handles(tables)
+  K, N = len(res), int(num_of_shards)
+  ids = _ids(ids)
+  if isinstance(fused_slot_size, torch.Tensor):
+    fused_slot_size = fused_slot_size.cpu().numpy()
+  fss = np.ascontiguousarray(fused_slot_size, dtype=np.int32).reshape(-1)
+  if fss.size != K * N:
+    raise _lib.MonolithHipError("len(fused_slot_size) / num_of_shards != len(table_handles)")
+  # (the library reads the ids later, on a stream of its own)
+  _fused_hint_keep.append(ids)
+  del _fused_hint_keep[:-8]
+  _lib.check(_lib.lib.mono_tables_fused_lookup_hint(
+      hs, C.c_int(K), _lib.vp(ids), C.c_void_p(fss.ctypes.data), C.c_int(N), C.c_int(ahead),
+      _lib.stream_ptr()))
+
+
 def fused_apply_gradient(tables: List, ids, fused_slot_size, id_grads, id_offsets, grad_offsets,
                          learning_rate_tensors, learning_rate_lengths, req_time, global_step,
                          num_of_shards: int, enable_grad_accumulation: bool = False):

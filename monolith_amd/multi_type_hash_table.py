@@ -104,6 +104,11 @@ class MultiTypeHashTable(BaseMultiTypeHashTable):
     return hash_table_ops.fused_lookup(self._hash_table_resources, ids, fused_slot_size,
                                        num_of_shards)
 
+  def fused_lookup_hint(self, ids, fused_slot_size, num_of_shards: int, ahead: int = 1) -> None:
+    """The fused_lookup `ahead` calls away, announced (hash_table_ops.fused_lookup_hint)."""
+    hash_table_ops.fused_lookup_hint(self._hash_table_resources, ids, fused_slot_size,
+                                     num_of_shards, ahead)
+
   def fused_apply_gradient(self, ids, fused_slot_size, id_grads, id_offsets, grad_offsets,
                            global_step, req_time, num_of_shards: int,
                            enable_grad_accumulation: bool = False) -> "MultiTypeHashTable":

@@ -92,7 +92,16 @@ def _random_fp16(rank, world):
   _random(rank, world, grad_bits=16)
 
 
-def _random(rank, world, grad_bits=32):
+def _random_pipelined(rank, world):
+  """The same stream with the reference's enable_pipelined_fwda2a switched on
+  (distributed_ps_sync.py:218-224): the first half of every next lookup — reorder, size exchange,
+  FID exchange — runs inside apply_gradients(next_slot_to_id=...), right after the update is
+  issued, and lookup() continues from it. Rows are still read after the update, so the
+  serial model must hold bit for bit (the reference's queues would serve stale rows here)."""
+  _random(rank, world, pipelined=True)
+
+
+def _random(rank, world, grad_bits=32, pipelined=False):
   """Each rank draws its own batch (duplicates inside a rank and across ranks, an empty slot,
   negative ids -> signed floor-mod routing). Lookup results and the owner-side table state after
   each step equal a serial simulation: per owner shard, contributions applied source-rank-major,
@@ -102,15 +111,19 @@ def _random(rank, world, grad_bits=32):
   from tests.dist_oracle_ops import OracleOps
   mk = lambda: {"a": cpu.seg(4, "adagrad"), "b": cpu.seg(2, "sgd"), "c": cpu.seg(3, "ftrl")}
   lrs = {"a": 0.1, "b": 0.5, "c": 0.01}
-  table = distributed_ps_sync.DistributedMultiTypeHashTableMpi(world, _table_factory(mk(), lrs),
-                                                               ops=OracleOps,
-                                                               grad_exchange_bits=grad_bits)
+  table = distributed_ps_sync.DistributedMultiTypeHashTableMpi(
+      world, _table_factory(mk(), lrs), ops=OracleOps, grad_exchange_bits=grad_bits,
+      queue_configs={"enable_pipelined_fwda2a": 1} if pipelined else None)
   # serial model of every owner shard (each rank simulates all of them)
   model = [{k: cpu.OracleTable([v]) for k, v in mk().items()} for _ in range(world)]
   for step in range(3):
     ids, grads = _batch(rank, step)
     slot_to_ids = {k: torch.from_numpy(v) for k, v in ids.items()}
-    emb, bundle = table.lookup(slot_to_ids, auxiliary_bundle={})
+    ahead = table.take_prefetched_reorder()
+    if pipelined and step > 0:
+      assert isinstance(ahead, distributed_ps_sync.ForwardPrefetch)
+    emb, bundle = table.lookup(slot_to_ids, auxiliary_bundle={},
+                               early_reorder_indicies_res_pack=ahead)
     for k, v in ids.items():
       exp = np.zeros((len(v), model[0][k].dim), np.float32)
       for n in range(world):
@@ -118,9 +131,10 @@ def _random(rank, world, grad_bits=32):
         if sel.any():
           exp[sel] = model[n][k].lookup(v[sel])
       assert np.array_equal(emb[k].numpy().view(np.uint32), exp.view(np.uint32)), (step, k)
+    nxt = {k: torch.from_numpy(v) for k, v in _batch(rank, step + 1)[0].items()} if pipelined else None
     table = table.apply_gradients(
         {k: (slot_to_ids[k], torch.from_numpy(grads[k])) for k in ids}, auxiliary_bundle=bundle,
-        global_step=step, req_time=100 + step)
+        global_step=step, req_time=100 + step, next_slot_to_id=nxt)
     for n in range(world):
       for src in range(world):
         s_ids, s_grads = _batch(src, step)
@@ -181,7 +195,7 @@ def _merged(rank, world):
   assert emb["slot1"].tolist() == [[-3.0 * world] * 2]
 
 
-@pytest.mark.parametrize("fn", [_basic, _random, _random_fp16, _merged],
+@pytest.mark.parametrize("fn", [_basic, _random, _random_fp16, _random_pipelined, _merged],
                          ids=lambda f: f.__name__)
 def test_world2_gloo(fn):
   _spawn(fn, 2)

@@ -40,7 +40,7 @@ def _batch(rank, step, shape="small"):
   return ids, grads
 
 
-def _worker(rank, world, port, q, backend="gloo", shape="small"):
+def _worker(rank, world, port, q, backend="gloo", shape="small", pipelined=0):
   try:
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -66,19 +66,26 @@ def _worker(rank, world, port, q, backend="gloo", shape="small"):
     if shape == "config4":
       opts = {"criteo": (64, entry.AdagradOptimizer(initial_accumulator_value=0.1), 0.01)}
     cfgs = {k: entry.HashTableConfigInstance(cfg(d, o), [lr]) for k, (d, o, lr) in opts.items()}
+    # pipelined: the reference's enable_pipelined_fwda2a (1), plus the owner's lookup hint (2)
+    qc = {"enable_pipelined_fwda2a": 1, "announce_owner_lookup": int(pipelined == 2)} if pipelined else None
     table = distributed_ps_sync.DistributedMultiTypeHashTableMpi(
         world, lambda idx: multi_type_hash_table.MultiTypeHashTable(
             cfgs, lambda slot, c: hash_table_ops.hash_table_from_config(
-                c, name_suffix="dg_%s_%d" % (slot, idx))))
+                c, name_suffix="dg_%s_%d" % (slot, idx))), queue_configs=qc)
     segs = {"a": cpu.seg(16, "adagrad"), "b": cpu.seg(2, "sgd"), "c": cpu.seg(3, "ftrl")}
     if shape == "config4":
       segs = {"criteo": cpu.seg(64, "adagrad")}
     lrs = {k: v[2] for k, v in opts.items()}
     model = [{k: cpu.OracleTable([v]) for k, v in segs.items()} for _ in range(world)]
-    for step in range(3 if shape == "small" else 2):
+    n_steps = (4 if pipelined else 3) if shape == "small" else 2
+    for step in range(n_steps):
       ids, grads = _batch(rank, step, shape)
       slot_to_ids = {k: torch.from_numpy(v).to(dev) for k, v in ids.items()}
-      emb, bundle = table.lookup(slot_to_ids, auxiliary_bundle={})
+      ahead = table.take_prefetched_reorder()
+      if pipelined and step > 0:
+        assert isinstance(ahead, distributed_ps_sync.ForwardPrefetch)
+      emb, bundle = table.lookup(slot_to_ids, auxiliary_bundle={},
+                                 early_reorder_indicies_res_pack=ahead)
       for k, v in ids.items():
         exp = np.zeros((len(v), model[0][k].dim), np.float32)
         for n in range(world):
@@ -86,9 +93,12 @@ def _worker(rank, world, port, q, backend="gloo", shape="small"):
           if sel.any():
             exp[sel] = model[n][k].lookup(v[sel])
         assert np.array_equal(emb[k].cpu().numpy().view(np.uint32), exp.view(np.uint32)), (step, k)
+      nxt = None
+      if pipelined and step + 1 < n_steps:
+        nxt = {k: torch.from_numpy(v).to(dev) for k, v in _batch(rank, step + 1, shape)[0].items()}
       table = table.apply_gradients(
           {k: (slot_to_ids[k], torch.from_numpy(grads[k]).to(dev)) for k in ids},
-          auxiliary_bundle=bundle, global_step=step, req_time=100 + step)
+          auxiliary_bundle=bundle, global_step=step, req_time=100 + step, next_slot_to_id=nxt)
       for n in range(world):
         for src in range(world):
           s_ids, s_grads = _batch(src, step, shape)
@@ -118,6 +128,13 @@ def _worker(rank, world, port, q, backend="gloo", shape="small"):
       assert np.array_equal(gi[go], ei[eo]), k
       assert np.array_equal(gr[go].view(np.uint32), er[eo].view(np.uint32)), k
       assert np.array_equal(gt[go], et[eo]), k
+    if pipelined == 2 and shape == "config4":  # one table: the announced lookups were served as such
+      import ctypes as C
+      from monolith_amd import _lib
+      counts = (C.c_int64 * 4)()
+      h = table._table._hash_tables["criteo"].table.h
+      _lib.check(_lib.lib.mono_table_path_counts(h, counts))
+      assert counts[2] >= 1, list(counts)
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()
@@ -139,6 +156,41 @@ def test_world2_exchange_on_hip_ops():
     p.join(timeout=30)
   for rank, err in res:
     assert err is None, "rank %d failed:\n%s" % (rank, err)
+
+
+@pytest.mark.parametrize("pipelined", [1, 2], ids=["fwda2a", "fwda2a+hint"])
+def test_world2_exchange_pipelined_forward(pipelined):
+  """queue_configs["enable_pipelined_fwda2a"] (distributed_ps_sync.py:218-224): the next batch's
+  reorder, size exchange and FID exchange (and, variant 2, the owner's lookup hint) run on a side
+  stream beside the update; lookup() continues from the ForwardPrefetch. Rows and the owner
+  shards' final state equal the serial oracle model bit for bit — nothing is stale."""
+  world = 2
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  ps = [ctx.Process(target=_worker, args=(r, world, port, q, "gloo", "small", pipelined))
+        for r in range(world)]
+  for p in ps:
+    p.start()
+  res = [q.get(timeout=150) for _ in ps]
+  for p in ps:
+    p.join(timeout=30)
+  for rank, err in res:
+    assert err is None, "rank %d failed:\n%s" % (rank, err)
+
+
+def test_world1_pipelined_forward_over_rccl():
+  """The pipelined forward with backend "nccl" (= RCCL) at world size 1, exchanges forced through
+  dist.all_to_all_single: the size and FID collectives are issued under the side stream, the
+  gradient and row collectives under the main one, as at N > 1. One table (config 4's shape), so
+  the owner's lookup hint takes effect."""
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q, "nccl", "config4", 2))
+  p.start()
+  rank, err = q.get(timeout=250)
+  p.join(timeout=30)
+  assert err is None, "rccl world-1 pipelined run failed:\n%s" % err
 
 
 def test_world2_exchange_config4_shape():
