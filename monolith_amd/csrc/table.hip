@@ -162,6 +162,9 @@ struct Table {
     bool chain_pending = false;   // a sort + classify chain was launched and the caller's stream
                                   // has not waited for it since
     bool hinted = false;          // built by mono_table_lookup_hint: valid only if d_flags[2] == 0
+    bool grouped_tail = false;    // the order's tail of absent ids is grouped by id (k_probe surrogates)
+    uint32_t sur_base = 0;        // ... whose sort keys start here (0: none); every k_classify of
+                                  // this order must know, or it takes them for slots
   } prep;
   // mono_table_lookup_hint: the slots and the update order of the NEXT lookups' ids (a queue of up
   // to kHintDepth, oldest first), resolved ahead on the table's chain streams while the current
@@ -203,6 +206,7 @@ struct Table {
   Workspace ws;
   Workspace ws_gated;  // the gated remainder of a write call with a hash filter
   int32_t* h_unk_cnt = nullptr;  // pinned: k_unk_count's per-chunk counts (write_path_gated)
+  bool gated_seen = false;       // the last write call went through a hash filter
   // mono_table_path_counts: [0] write calls served by a prepared order, [1] write calls that
   // tried one and fell back, [2] lookups served by a hint, [3] hint queues dropped non-empty
   int64_t path_counts[4] = {0, 0, 0, 0};
@@ -441,7 +445,10 @@ __global__ void __launch_bounds__(256) k_probe(TableDev t, const int64_t* __rest
                                                uint32_t* __restrict__ cache_slots,
                                                uint32_t* __restrict__ blk_miss,
                                                uint32_t* __restrict__ zero8,
-                                               uint32_t* __restrict__ miss_total) {
+                                               uint32_t* __restrict__ miss_total,
+                                               uint32_t* __restrict__ sort_key,
+                                               uint32_t* __restrict__ sur_cells, uint32_t sur_mask,
+                                               uint32_t sur_base) {
   __shared__ uint32_t s_miss;
   if (threadIdx.x == 0) s_miss = 0;
   if (blockIdx.x == 0 && threadIdx.x < 16) zero8[threadIdx.x] = 0;  // counters of the prepared queues
@@ -474,6 +481,33 @@ __global__ void __launch_bounds__(256) k_probe(TableDev t, const int64_t* __rest
       cache_ids[i0 + sub] = mine;
       cache_slots[i0 + sub] = my_slot;
       missed += my_slot == kNoSlot;
+      // Behind a hash filter the ids the table does not hold are what the update gates, one group
+      // per distinct id: they get a sort key of their own above every slot — sur_base + the
+      // position that first claimed the id's cell in a scratch hash set (4-byte cells holding a
+      // position, the id itself is ids[position]) — so that the update order's sort leaves them
+      // grouped by id, in input order, behind the known ids, at no extra pass.
+      if (sort_key) {
+        uint32_t k = my_slot;
+        if (my_slot == kNoSlot) {
+          const uint32_t me = (uint32_t)(i0 + sub);
+          uint32_t c = (uint32_t)(mix64((uint64_t)mine ^ 0x9E3779B97F4A7C15ull) >> 24) & sur_mask;
+          uint32_t leader = me;
+          for (;;) {
+            uint32_t v = __hip_atomic_load(&sur_cells[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v == 0xFFFFFFFFu) {
+              v = atomicCAS(&sur_cells[c], 0xFFFFFFFFu, me);
+              if (v == 0xFFFFFFFFu) break;  // claimed: this position leads the id's group
+            }
+            if (ids[v] == mine) {
+              leader = v;
+              break;
+            }
+            c = (c + 1) & sur_mask;
+          }
+          k = sur_base + leader;
+        }
+        sort_key[i0 + sub] = k;
+      }
     }
   }
   // ids not found: summed per workgroup (LDS), one plain store each; k_verify adds them up
@@ -900,6 +934,7 @@ struct ApplyArgs {
   const int32_t* cls_dim;
   int want_dim;      // 0 = every segment
   uint32_t skip_slot;  // sorted key that marks "no destination" (besides kNoSlot)
+  uint32_t sur_base;   // != 0: sorted keys >= sur_base stand for ids the table did not hold (k_probe)
   // packed sources (segment_set_sum_packed): occurrence value = class | sample << pk_sbits |
   // seq << pk_qshift; its row = src_tab[class].base + sample * stride + seq * seq_stride, its class
   // (k_classify's width filter) = value & pk_smask
@@ -1282,7 +1317,7 @@ __global__ void __launch_bounds__(256, 8) k_apply(TableDev t, ApplyArgs a) {
       const uint32_t prev = j > 0 ? sk[j - 1] : ~slot;
       const uint32_t next = j + 1 < a.n ? sk[j + 1] : ~slot;
       if (prev == slot) return;
-      if (slot == kNoSlot) return;
+      if (slot == kNoSlot || (a.sur_base != 0u && slot >= a.sur_base)) return;
       end = next != slot ? j + 1 : segment_end<uint32_t>(sk, j, a.n, slot);
     }
   } else {
@@ -1589,7 +1624,8 @@ __global__ void __launch_bounds__(kClsThreads) k_classify(ApplyArgs a, int allow
       idxv[k] = a.sidx[j];
       const uint32_t prev = j > 0 ? sk[j - 1] : ~slot;
       const uint32_t next = j + 1 < n ? sk[j + 1] : ~slot;
-      bool keep = prev != slot && slot != kNoSlot && slot != a.skip_slot;
+      bool keep = prev != slot && slot != kNoSlot && slot != a.skip_slot &&
+                  (a.sur_base == 0u || slot < a.sur_base);
       if (keep && a.want_dim)
         keep = a.cls_dim[a.src_tab ? (idxv[k] & a.pk_smask) : a.cls[idxv[k]]] == a.want_dim;
       if (keep) {
@@ -2941,18 +2977,35 @@ static int lookup_prepared(Table* t, Table::Prep& p, const int64_t* ids, int64_t
   // adds to (a stale increment would make the next k_apply read heads nobody wrote).
   if (p.chain_pending && !hint) MONO_HIP(hipStreamWaitEvent(st, p.ev_ready, 0));
   const size_t n_al = ((size_t)n + 63) & ~(size_t)63;
-  const int end_bit = bits_for(t->d.cap + 1);
+  // Behind a hash filter (the last write call was gated): sort keys of their own, absent ids
+  // grouped by surrogate keys sur_base + position (k_probe). sur_base lies above the two
+  // special-key slots cap and cap + 1.
+  const uint64_t sur_base64 = t->d.cap + 2;
+  const bool sur = t->gated_seen && sur_base64 + (uint64_t)n < 0xFFFFFFF0ull;
+  uint64_t sur_cells_n = 0;
+  if (sur) {
+    sur_cells_n = 1024;
+    while (sur_cells_n < 2 * (uint64_t)n) sur_cells_n <<= 1;
+  }
+  const int end_bit = sur ? bits_for(sur_base64 + (uint64_t)n) : bits_for(t->d.cap + 1);
   const size_t tmp_bytes = (sort_pairs_tmp_bytes((size_t)n, end_bit) + 255) & ~(size_t)255;
-  const size_t q_bytes = queue_bytes(n, t->d.dim);
-  MONO_TRY(p.ws.ensure(2 * n_al * sizeof(uint32_t) + tmp_bytes + q_bytes));
+  const size_t q_bytes = (queue_bytes(n, t->d.dim) + 255) & ~(size_t)255;
+  const size_t sur_bytes = sur ? (n_al + (size_t)sur_cells_n) * sizeof(uint32_t) : 0;
+  MONO_TRY(p.ws.ensure(2 * n_al * sizeof(uint32_t) + tmp_bytes + q_bytes + sur_bytes));
   p.sslots = (uint32_t*)p.ws.ptr;
   p.sidx = p.sslots + n_al;
   void* tmp = p.sidx + n_al;
   p.q_base = (char*)tmp + tmp_bytes;
+  uint32_t* sort_in = sur ? (uint32_t*)(p.q_base + q_bytes) : nullptr;
+  uint32_t* sur_cells = sur ? sort_in + n_al : nullptr;
+  p.grouped_tail = sur;
+  p.sur_base = sur ? (uint32_t)sur_base64 : 0u;
   double hp = host_prof_on() ? host_now() : 0.0;
   p.probe_blocks = grid_for(n, 32 * kIlpP, kProbeMaxBlocks);
+  if (sur) MONO_HIP(hipMemsetAsync(sur_cells, 0xFF, (size_t)sur_cells_n * sizeof(uint32_t), ps));
   hipLaunchKernelGGL(k_probe, dim3(p.probe_blocks), dim3(256), 0, ps, t->d, ids, n, rec_ids, rec_slots,
-                     p.d_blk_miss, (uint32_t*)p.q_base, p.d_flags);
+                     p.d_blk_miss, (uint32_t*)p.q_base, p.d_flags, sort_in, sur_cells,
+                     (uint32_t)(sur_cells_n ? sur_cells_n - 1 : 0), (uint32_t)sur_base64);
   MONO_HIP(hipGetLastError());
   host_tick("lookup: launch probe", &hp);
   MONO_HIP(hipEventRecord(p.ev_probe, ps));
@@ -2985,11 +3038,12 @@ static int lookup_prepared(Table* t, Table::Prep& p, const int64_t* ids, int64_t
   // update order beside it
   if (!hint) MONO_HIP(hipStreamWaitEvent(ss, p.ev_probe, 0));
   host_tick("lookup: ss wait probe", &hp);
-  MONO_TRY(sort_pairs_u32(rec_slots, p.sslots, nullptr, p.sidx, (size_t)n, end_bit, tmp, tmp_bytes,
-                          ss));
+  MONO_TRY(sort_pairs_u32(sur ? sort_in : rec_slots, p.sslots, nullptr, p.sidx, (size_t)n, end_bit, tmp,
+                          tmp_bytes, ss));
   host_tick("lookup: sort launches", &hp);
   ApplyArgs a{};
   a.skip_slot = kNoSlot;
+  a.sur_base = sur ? (uint32_t)sur_base64 : 0u;
   a.n = n;
   a.skeys = p.sslots;
   a.sidx = p.sidx;
@@ -3047,6 +3101,7 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
       pa.src = src;
       pa.mode = mode;
       pa.skeys = p.sslots;
+      pa.sur_base = p.sur_base;
       pa.sidx = p.sidx;
       uint4* heads0 = nullptr;
       MONO_TRY(queue_setup(&pa, p.q_base, n, t->d.dim, &heads0, st, /*counters_cleared=*/true));
@@ -3078,6 +3133,7 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
     a.sort_err = sort_error_word();
     for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
     a.skeys = p.sslots;
+    a.sur_base = p.sur_base;
     a.sidx = p.sidx;
     a.guard = p.d_flags;
     a.guard_seen = p.seen_changed;
@@ -3147,6 +3203,7 @@ static int try_prepared(Table* t, const int64_t* ids, const float* src, int64_t 
   a.sort_err = sort_error_word();
   for (int s = 0; s < kMaxSeg; ++s) a.lr[s] = s < n_lrs ? lrs[s] : 0.f;
   a.skeys = p.sslots;
+  a.sur_base = p.sur_base;
   a.sidx = p.sidx;
   uint4* heads = nullptr;
   // (prepared classification: its counters stand; k_verify has reset the hand-out cursor)
@@ -3175,7 +3232,7 @@ static int unk_count(const uint32_t* flag, int64_t n, int32_t* cnt, hipStream_t 
 }
 static int gated_unknown(Table* t, const ApplyArgs& a, const int64_t* ids, int64_t n,
                          const uint32_t* flag, const int32_t* cnt, const uint32_t* order_tail,
-                         int64_t U, hipStream_t st) {
+                         int64_t U, hipStream_t st, bool tail_grouped = false) {
   if (U > 0) {
     const size_t u_al = ((size_t)U + 63) & ~(size_t)63;
     const size_t tmp64 = (group_keys64_tmp_bytes((size_t)U) + 255) & ~(size_t)255;
@@ -3188,7 +3245,12 @@ static int gated_unknown(Table* t, const ApplyArgs& a, const int64_t* ids, int64
     uint32_t* idx_out2 = unk_idx + u_al;
     char* tmp2 = (char*)(idx_out2 + u_al);
     char* q_base2 = tmp2 + tmp64;
-    if (order_tail) {
+    if (order_tail && tail_grouped) {
+      // (the lookup's probe gave every absent id a sort key of its own: the tail is grouped by id
+      // already, input order inside a group — it IS the walk's order)
+      hipLaunchKernelGGL(k_unk_from_order, dim3(grid_for(U, 256)), dim3(256), 0, st, ids, order_tail, U,
+                         n, key_out, idx_out2);
+    } else if (order_tail) {
       hipLaunchKernelGGL(k_unk_from_order, dim3(grid_for(U, 256)), dim3(256), 0, st, ids, order_tail, U,
                          n, unk_ids, unk_idx);
     } else {
@@ -3199,7 +3261,8 @@ static int gated_unknown(Table* t, const ApplyArgs& a, const int64_t* ids, int64
     MONO_HIP(hipGetLastError());
     // grouped by id (input order inside a group), not sorted: the gated walk only asks where a
     // group starts and ends
-    MONO_TRY(group_keys64(unk_ids, unk_idx, key_out, idx_out2, (size_t)U, tmp2, tmp64, st));
+    if (!(order_tail && tail_grouped))
+      MONO_TRY(group_keys64(unk_ids, unk_idx, key_out, idx_out2, (size_t)U, tmp2, tmp64, st));
     ApplyArgs g = a;
     g.n = U;
     g.from_keys = 1;
@@ -3290,7 +3353,7 @@ static int gated_after_prepared(Table* t, void* filter, const ApplyArgs& a, cons
     hipStream_t gs = p.stream;
     MONO_HIP(hipStreamWaitEvent(gs, p.ev_verify, 0));  // (the ids are final, the slot record read)
     MONO_HIP(hipStreamWaitEvent(gs, p.ev_ready, 0));   // (the order is complete)
-    MONO_TRY(gated_unknown(t, a, ids, n, nullptr, nullptr, p.sidx + (n - U), U, gs));
+    MONO_TRY(gated_unknown(t, a, ids, n, nullptr, nullptr, p.sidx + (n - U), U, gs, p.grouped_tail));
     MONO_HIP(hipEventRecord(p.ev_gated, gs));
     MONO_HIP(hipStreamWaitEvent(st, p.ev_gated, 0));
   }
@@ -3309,6 +3372,7 @@ static int write_path(Table* t, void* filter, const int64_t* ids, const float* s
   FilterDev fd{};
   if (filter) MONO_TRY(filter_dev_view(filter, &fd, st));
   const bool from_keys = fd.kind != 0;
+  t->gated_seen = from_keys;
   // "one lookup, then an update of as many ids" is what makes the next lookup prepare the update
   // order; two prepared orders in a row that could not be used (other ids, ids to insert) switch
   // it off again for a while
