@@ -979,8 +979,9 @@ def main():
                    "traffic_source": traffic_src, "algorithmic_bytes": kern[dom][1],
                    "kernel_note": "k_apply = the sub-group apply kernel alone (segments of <= 96 "
                                   "occurrences), timed with HIP events on the stream it runs on; "
-                                  "'apply phase' = k_classify, then k_apply beside k_apply_long "
-                                  "(hot keys) + k_combine, on the caller's stream",
+                                  "'apply phase' = k_verify's verdict, then k_apply beside "
+                                  "k_long_pack -> k_long_chain (hot keys, summed in input order), "
+                                  "joined on the caller's stream",
                    "long_segment_occurrences": n_long, "long_segment_keys": u_long,
                    "measured_random_access_ceiling": measured_ceiling(),
                    "kernel_ms": {k: v[0] for k, v in kern.items()},
