@@ -685,7 +685,8 @@ def main_config5(args, device):
                              "second slot expires after 1 day, expiry eviction after timed steps %d "
                              "and %d%s" %
                              (total_rows, args.batch, recur, ev_every, 2 * ev_every,
-                              ", the next batch's ids announced by lookup_hint" if ahead else ""),
+                              ", the ids of the next %d batches announced by lookup_hint" % ahead
+                              if ahead else ""),
                  "fids_per_step": n, "unique_ratio": uniq, "fresh_fids_per_step": n_fresh,
                  "rows_before": rows0, "rows_after": rows1, "stale_rows_planted": stale,
                  "inserted_rows": inserted, "inserted_per_step": inserted / float(args.warmup + args.steps),
@@ -759,9 +760,11 @@ def main():
   ap.add_argument("--no-hint", action="store_true",
                   help="config 2: do not announce the next batch's ids (mono_table_lookup_hint) "
                        "between a step's lookup and its update")
-  ap.add_argument("--c5-hint-ahead", type=int, default=1,
+  ap.add_argument("--c5-hint-ahead", type=int, default=3,
                   help="config 5: lookups announced ahead (0..3; --no-hint = 0)")
-  ap.add_argument("--hint-ahead", type=int, default=2, help="config 2: lookups announced ahead (1..3)")
+  # (three ahead: 318 against 324 us with two, config 5 0.50 against 0.55 ms with one and 0.61 with
+  # two — the hinted chains run 3-5x slower beside the apply kernels than alone and need the room)
+  ap.add_argument("--hint-ahead", type=int, default=3, help="config 2: lookups announced ahead (1..3)")
   ap.add_argument("--config", type=int, default=0, help="2 | 3 | 4 | 5 (default: 2, or 4 when N > 1)")
   ap.add_argument("--dim", type=int, default=0, help="config 4 / --sharded: row width (default 64 / 16)")
   args = ap.parse_args()
@@ -969,8 +972,8 @@ def main():
       "config": {"workload": "criteo-shaped: 26 single-hot slots, %.3g-row table, dim 16 fp32, "
                              "batch %d, Adagrad, lookup + apply_gradients(dedup)%s" %
                              (total_rows, args.batch,
-                              "" if args.no_hint else ", the next two batches' ids announced by "
-                              "lookup_hint"),
+                              "" if args.no_hint else ", the ids of the next %d batches announced "
+                              "by lookup_hint" % args.hint_ahead),
                  "fids_per_step": n, "unique_ratio": uniq, "skew": args.skew,
                  "parallelism": "independent table per GPU" if world > 1 else "1 GPU",
                  "populate_s": t_pop, "table_rows": rows_live},
