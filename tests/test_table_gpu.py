@@ -90,14 +90,25 @@ def test_random_stream_bit_exact(name, dedup):
   assert o.max_update_ts() == h.max_update_ts()
 
 
-@pytest.mark.parametrize("name", ["adagrad16", "ftrl6", "multi3", "adagrad64"])
+# (the widths and optimizer templates the chain kernel is instantiated for, beside CFGS')
+HOT_CFGS = dict(CFGS, **{
+    "sgd16": {"segments": [{"dim": 16, "opt": "sgd", "init": "constant", "init_a": 0.25}]},
+    "adagrad8": {"segments": [{"dim": 8, "opt": "adagrad", "init": "uniform", "init_a": -0.05,
+                               "init_b": 0.05}], "seed": 3},
+    "adagrad32": {"segments": [{"dim": 32, "opt": "adagrad", "init": "uniform", "init_a": -0.05,
+                                "init_b": 0.05}], "seed": 5},
+})
+
+
+@pytest.mark.parametrize("name", ["adagrad16", "ftrl6", "multi3", "adagrad64", "ftrl16", "sgd16",
+                                  "adagrad8", "adagrad32"])
 def test_hot_keys_in_reference_order(name):
   """Keys with thousands of occurrences in a batch (9001 and exactly 4096 here): every sum runs
   in the reference's order at any length (embedding_hash_table_tf_bridge.cc:241-266 sums a key's
   gradients sequentially), so EVERY row is bit-exact — dedup on and off, assign_add — over several
   steps with no re-synchronisation of the hot rows. (Rows of width 8 / 16 / 32 / 64 go through
   k_long_pack + k_long_chain, the others through k_apply_long.)"""
-  cfg = CFGS[name]
+  cfg = HOT_CFGS[name]
   o, h, _, _ = _pair(cfg)
   rng = np.random.Generator(np.random.PCG64(11))
   D, nseg = o.dim, len(cfg["segments"])
