@@ -4,7 +4,6 @@
 // ops/hash_filter_intercept_gradient_op.cc:39-62.
 #include <algorithm>
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <vector>
 
 #include "filter_dev.h"

@@ -23,8 +23,9 @@
 #include <ctime>
 #include <cstdlib>
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <vector>
+
+#include <hip/hip_fp16.h>
 
 #include "filter_dev.h"
 #include "mono_common.h"
@@ -956,7 +957,7 @@ struct ApplyArgs {
                              // [8 .. 13] very long entries per length class
   struct SplitSeg* cqueue;   // keys whose segment was cut into chunks, finished by k_combine
   float* partials;           // [partial row][dim] chunk sums of the split keys
-  int chunk;                 // occurrences above which a key is split (kChunk)
+  int chunk;                 // occurrences above which a key is split (chunk_size(): 1 << 30 = never)
   const uint4* heads;        // compacted (position, length, slot, first index) of the short
                              // segments, or nullptr
   const uint32_t* nheads;
@@ -1031,11 +1032,10 @@ constexpr uint32_t kNoPart = 0xFFFFFFFFu;
 #define MONO_LONG_SEG 96
 #endif
 constexpr int kLongSeg = MONO_LONG_SEG;       // occurrences above which a segment goes to k_apply_long
-// A key with more than kChunk occurrences in one batch is summed in near-equal chunks of at most
-// kChunk occurrences (each chunk in input order, by its own workgroup); k_combine then adds the
-// chunk sums in chunk order. This is the one place the summation order differs from the
-// sequential reference (DESIGN.md "hot keys"); MODE_OPT_SEQ is never split.
-constexpr int kChunk = 4096;
+// Only under MONO_CHUNK=<rows> (chunk_size(); off by default): a key with more occurrences than
+// that in one batch is summed in near-equal chunks (each in input order), k_combine then adds the
+// chunk sums in chunk order — the one form whose summation order differs from the sequential
+// reference. MODE_OPT_SEQ is never split.
 constexpr int kLongMaxDim = 512;   // wider rows stay on the sub-group path
 constexpr int kPackRows = 64;      // rows per packed block = one loop iteration of chain_sum
 constexpr int kVeryLong = 2048;    // occurrences above which a chain gets a CU to itself
