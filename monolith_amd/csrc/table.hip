@@ -206,6 +206,7 @@ struct Table {
   int32_t* slot_expire_dev = nullptr;
   Workspace ws;
   Workspace ws_gated;  // the gated remainder of a write call with a hash filter
+  Workspace ws_pack_gated;  // ... and the packed rows of its hot ids
   int32_t* h_unk_cnt = nullptr;  // pinned: k_unk_count's per-chunk counts (write_path_gated)
   bool gated_seen = false;       // the last write call went through a hash filter
   // mono_table_path_counts: [0] write calls served by a prepared order, [1] write calls that
@@ -2729,8 +2730,11 @@ static int chain_setup(Table* t, ApplyArgs& a, bool allow_long) {
   if (!allow_long || !chain_ok(t, a.mode)) return 0;
   const size_t need = packed_blocks_bound(a.n) * kPackRows * (size_t)t->d.dim * sizeof(float) + 65536;
   if (need >= 0xFFFF0000ull) return 0;  // (32-bit buffer offsets)
-  MONO_TRY(t->ws_pack.ensure(need));
-  a.packed = (float*)t->ws_pack.ptr;
+  // (the gated remainder of a write call runs beside the known ids' chains, on another stream:
+  // a pack buffer of its own)
+  Workspace& ws = a.from_keys ? t->ws_pack_gated : t->ws_pack;
+  MONO_TRY(ws.ensure(need));
+  a.packed = (float*)ws.ptr;
   a.packed_bytes = (uint32_t)need;
   return 0;
 }
@@ -4005,6 +4009,7 @@ int mono_table_destroy(void* table) {
   t->ws.release();
   t->ws_gated.release();
   t->ws_pack.release();
+  t->ws_pack_gated.release();
   if (t->h_unk_cnt) (void)hipHostFree(t->h_unk_cnt);
   for (int i = 0; i < 4; ++i)
     if (t->ev[i]) (void)hipEventDestroy(t->ev[i]);

@@ -518,6 +518,13 @@ def test_gated_update_keeps_the_hinted_order_under_insertions(depth):
     assert hi_k < 4096
     k = r.integers(0, hi_k, n)
     k[r.integers(0, n, n // 5)] = 3          # a hot id (long segment beside the gated remainder)
+    # ... and two bursts of ids nobody knows yet, this step's and the one before's: on its second
+    # sight a burst id is admitted with hundreds of occurrences — a chain in the gated remainder
+    # (pack buffer of its own) beside the known hot id's chain
+    pos = r.permutation(n)
+    k[pos[:600]] = 3900 + step
+    if step > 0:
+      k[pos[600:1100]] = 3900 + step - 1
     return fid(k)
 
   known = np.repeat(fid(np.arange(base)), 5)   # (five occurrences: past the gate's threshold)
@@ -550,10 +557,10 @@ def test_gated_update_keeps_the_hinted_order_under_insertions(depth):
   counts = (C.c_int64 * 4)()
   _lib.check(_lib.lib.mono_table_path_counts(h.t.table.h, counts))
   # every update ran on the order its lookup (hinted, from the second step on) had prepared,
-  # except the first and the one at which the growing table rehashed (that one drops the queue);
-  # none tried a prepared order and had to fall back
-  assert counts[0] >= steps - 2 and counts[1] == 0, list(counts)
-  assert counts[2] >= steps - 3 and counts[3] <= 1, list(counts)
+  # except the first and those at which the growing table rehashed (they drop the queue; twice
+  # here); none tried a prepared order and had to fall back
+  assert counts[0] >= steps - 4 and counts[1] == 0, list(counts)
+  assert counts[2] >= steps - 5 and counts[3] <= 2, list(counts)
   probe = np.unique(batch(steps - 1))
   assert np.array_equal(of.get(probe), hf.get(torch.as_tensor(probe).cuda()).cpu().numpy())
 
