@@ -177,7 +177,13 @@ class DistributedMultiTypeHashTableMpi(multi_type_hash_table.BaseMultiTypeHashTa
       if ahead.event is not None:  # (its kernels and collectives ran on the side stream)
         cur = torch.cuda.current_stream(ahead.id_flat_t.device)
         cur.wait_event(ahead.event)
-        ahead.id_flat_t.record_stream(cur)  # (allocated under the side stream, read here)
+        # (allocated under a side stream, read on this one from here on: the ids the owner looks
+        # up, the reorder's id list and its embedding offsets)
+        ahead.id_flat_t.record_stream(cur)
+        all_fids_, _, _, offs_ = ahead.pack
+        for t_ in [all_fids_] + list(offs_):
+          if isinstance(t_, torch.Tensor) and t_.is_cuda:
+            t_.record_stream(cur)
     if early_reorder_indicies_res_pack:
       if hasattr(early_reorder_indicies_res_pack, "result"):  # a reorder still in flight
         early_reorder_indicies_res_pack = early_reorder_indicies_res_pack.result()
