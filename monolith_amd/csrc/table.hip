@@ -16,9 +16,11 @@
 // bucket (one coalesced 64 B access), vote with a wave ballot, then move the row with the same
 // 8 lanes (coalesced 8/16 B per lane). Inserts claim a slot with a 64-bit atomicCAS.
 // Writers never race on a row: every write path first groups occurrences by slot (stable LSD
-// radix sort of 32-bit slots, or of the 64-bit keys when a hash filter gates inserts) and one
-// sub-group walks a key's occurrences in input order — which is also what makes duplicate
-// handling bit-exact with the reference's sequential loops (SURVEY.md §8a closed forms).
+// radix sort of 32-bit slots; behind a hash filter the ids the table does not hold are grouped by
+// id instead) and one sub-group walks a key's occurrences in input order — a key with more than
+// 96 of them goes to one wave of k_long_chain, which adds its packed rows in the same order —
+// which is also what makes duplicate handling bit-exact with the reference's sequential loops at
+// any number of occurrences (SURVEY.md §8a closed forms; bridge :241-266).
 #include <algorithm>
 #include <ctime>
 #include <cstdlib>
