@@ -201,6 +201,12 @@ def test_world2_gloo(fn):
   _spawn(fn, 2)
 
 
+def test_world3_gloo_pipelined():
+  """Three ranks (not a power of two: floormod routing of negative ids over an odd modulus), the
+  pipelined forward switched on."""
+  _spawn(_random_pipelined, 3)
+
+
 def test_world1_no_process_group():
   """shard_num 1 without torch.distributed initialised: the exchanges are identities."""
   _basic(0, 1)
